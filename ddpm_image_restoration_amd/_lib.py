@@ -1,0 +1,73 @@
+"""ctypes binding of libddpmir.so (include/ddpmir.h).  No fallback: a missing library is an error."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libddpmir.so")
+
+CODEC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int,
+                       C.c_int)
+
+
+class Config(C.Structure):
+    _fields_ = [("arch", C.c_int), ("dtype", C.c_int), ("attn_min_level", C.c_int), ("device", C.c_int),
+                ("use_graph", C.c_int)]
+
+
+class LoopOpts(C.Structure):
+    _fields_ = [("codec", CODEC_FN), ("codec_user", C.c_void_p), ("noise", C.c_void_p), ("seed", C.c_uint64),
+                ("image_offset", C.c_uint64), ("trace", C.c_void_p), ("noise_coeff", C.c_float),
+                ("phase_q", C.c_int), ("phase_every", C.c_int), ("phase_alpha", C.c_float)]
+
+
+# every symbol include/ddpmir.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "ddpmir_create": (C.c_void_p, [C.POINTER(Config)]),
+    "ddpmir_destroy": (None, [C.c_void_p]),
+    "ddpmir_last_error": (C.c_char_p, [C.c_void_p]),
+    "ddpmir_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "ddpmir_weight_blob_bytes": (C.c_size_t, [C.c_void_p]),
+    "ddpmir_finalize_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "ddpmir_param_count": (C.c_int64, [C.c_void_p]),
+    "ddpmir_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_int, C.c_void_p]),
+    "ddpmir_ddrm_sample_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_float, C.c_float, C.POINTER(LoopOpts)]),
+    "ddpmir_create_eps_unet": (C.c_void_p, [C.c_int]),
+    "ddpmir_predict_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "ddpmir_p_sample_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_int]),
+    "ddpmir_phase_consistency": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_float]),
+    "ddpmir_jpeg_roundtrip_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ddpmir_last_forward_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "ddpmir_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libddpmir.so and bind every declared symbol.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950).  There is no CPU fallback for the restoration path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(lib, ctx, rc: int, what: str):
+    if rc != 0:
+        msg = lib.ddpmir_last_error(ctx)
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,58 @@
+// Common definitions for the gfx950 (MI355X) restoration sampler kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+namespace ddpmir {
+
+// ---- activation codes shared by prologues / epilogues
+enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_LRELU = 3, ACT_RELU = 4, ACT_SIGMOID = 5, ACT_TANH = 6 };
+// ---- static in-block frequency masks (webp_inference.py:241-252)
+enum MaskMode : int { MASK_NONE = 0, MASK_LOW = 1, MASK_HIGH = 2 };
+// ---- output store layouts
+enum StoreMode : int { STORE_NHWC = 0, STORE_NCHW = 1 };
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case ACT_SILU: return v / (1.0f + __expf(-v));
+    case ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+    case ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// low-frequency membership of pixel (y,x) for block size bs and corner size `low`, including the
+// partial-block rule low_size = max(1, min(low, i_end-i, j_end-j))  (webp_inference.py:247)
+__device__ __forceinline__ bool is_low_freq(int y, int x, int H, int W, int bs, int low) {
+  int iy = y % bs, ix = x % bs;
+  int by = y - iy, bx = x - ix;
+  int eh = min(bs, H - by), ew = min(bs, W - bx);
+  int ls = max(1, min(low, min(eh, ew)));
+  return iy < ls && ix < ls;
+}
+
+struct Status {
+  int code = 0;
+  std::string msg;
+};
+
+#define DDPMIR_HIP_CHECK(expr)                                                                     \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      char _b[512];                                                                                \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      throw std::runtime_error(_b);                                                                \
+    }                                                                                              \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+}  // namespace ddpmir

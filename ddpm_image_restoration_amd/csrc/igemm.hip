@@ -1,0 +1,206 @@
+// Implicit-GEMM convolution / linear kernel, exact fp32 on the gfx950 matrix cores.
+//
+//   out[m][n] = epi( sum_{tap} sum_{c} pro(A[pixel(m) + tap][c]) * Wt[tap][n][c] )
+//
+// M = B*H*W output pixels (NHWC rows), N = Cout, K = taps*Cin.  One workgroup (4 waves) owns a
+// 128 x (32*NT) output tile; each wave owns 32 rows x 32*NT columns as NT 32x32 accumulators of
+// v_mfma_f32_32x32x2_f32 (bit-exact fp32 fma chain, MI355X_MICROARCH "FP32-input MFMA").  K is walked in
+// 32-channel chunks per tap; the next chunk's global loads are issued into registers before the current
+// chunk's MFMAs (issue-early / write-late staging) and the GroupNorm affine + activation of the producer
+// layer is applied on the way into LDS, so normalised tensors are never materialised in HBM.
+//
+// LDS image: row-major [row][32 k + 4 pad] floats; a lane reads 16 B = 4 consecutive k of its row
+// (ds_read_b128; the 36-float row stride is conflict-free for the 16-lane b128 groups).  Within a chunk
+// the k order seen by the MFMA is permuted (lane half h takes k = 8g+4h+j) -- identical for A and B.
+#include "kernels.h"
+
+namespace ddpmir {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LROW = BK + 4;
+
+template <int NT>
+__global__ __launch_bounds__(256) void igemm_kernel(const IGemm p) {
+  __shared__ __attribute__((aligned(16))) float As[BM * LROW];
+  __shared__ __attribute__((aligned(16))) float Bs[NT * 32 * LROW];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int q = tid & 7;        // 16-byte chunk inside the 32-float k chunk
+  const int r0 = tid >> 3;      // 0..31
+  const int M = p.B * p.H * p.W;
+  const int HW = p.H * p.W;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * (NT * 32);
+  const int nck = (p.Cin + BK - 1) / BK;
+  const int nit = p.taps * nck;
+  const bool affine = p.scale != nullptr;
+
+  // per-thread A rows
+  int a_b[4], a_y[4], a_x[4];
+  bool a_ok[4];
+  size_t a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + r0 + 32 * i;
+    bool ok = m < M;
+    int mm = ok ? m : 0;
+    int b = mm / HW, rem = mm - b * HW;
+    int y = rem / p.W, x = rem - y * p.W;
+    if (ok && p.pro_mask != MASK_NONE) {
+      bool lowp = is_low_freq(y, x, p.H, p.W, p.bs, p.low);
+      ok = (p.pro_mask == MASK_LOW) ? lowp : !lowp;
+    }
+    a_b[i] = b; a_y[i] = y; a_x[i] = x; a_ok[i] = ok;
+    a_off[i] = (size_t)mm * p.lda;
+  }
+
+  float4 a_reg[4], s_reg[4], h_reg[4], b_reg[NT];
+  bool a_val[4];
+
+  auto gload = [&](int it) {
+    int tap = it / nck;
+    int c = (it - tap * nck) * BK + 4 * q;
+    int dy = 0, dx = 0;
+    if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+    bool cok = c < p.Cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bool ok = a_ok[i] && cok && (unsigned)(a_y[i] + dy) < (unsigned)p.H && (unsigned)(a_x[i] + dx) < (unsigned)p.W;
+      a_val[i] = ok;
+      a_reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        a_reg[i] = *reinterpret_cast<const float4*>(p.A + a_off[i] + (ptrdiff_t)(dy * p.W + dx) * p.lda + c);
+        if (affine) {
+          s_reg[i] = *reinterpret_cast<const float4*>(p.scale + (size_t)a_b[i] * p.Cin + c);
+          h_reg[i] = *reinterpret_cast<const float4*>(p.shift + (size_t)a_b[i] * p.Cin + c);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      int n = n0 + r0 + 32 * i;
+      b_reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < p.Cout && cok)
+        b_reg[i] = *reinterpret_cast<const float4*>(p.Wt + ((size_t)tap * p.Cout + n) * p.Cin + c);
+    }
+  };
+
+  auto lds_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = a_reg[i];
+      if (a_val[i]) {
+        if (affine) {
+          v.x = fmaf(v.x, s_reg[i].x, h_reg[i].x); v.y = fmaf(v.y, s_reg[i].y, h_reg[i].y);
+          v.z = fmaf(v.z, s_reg[i].z, h_reg[i].z); v.w = fmaf(v.w, s_reg[i].w, h_reg[i].w);
+        }
+        if (p.pro_act != ACT_NONE) {
+          v.x = act_apply(v.x, p.pro_act); v.y = act_apply(v.y, p.pro_act);
+          v.z = act_apply(v.z, p.pro_act); v.w = act_apply(v.w, p.pro_act);
+        }
+      }
+      *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LROW + 4 * q]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LROW + 4 * q]) = b_reg[i];
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int lr = lane & 31;
+  const int lh = lane >> 5;
+  const float* a_rd = &As[(wave * 32 + lr) * LROW + 4 * lh];
+  const float* b_rd = &Bs[lr * LROW + 4 * lh];
+
+  gload(0);
+  for (int it = 0; it < nit; ++it) {
+    lds_store();
+    __syncthreads();
+    if (it + 1 < nit) gload(it + 1);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      float4 a4 = *reinterpret_cast<const float4*>(a_rd + 8 * g);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float4 b4 = *reinterpret_cast<const float4*>(b_rd + nt * 32 * LROW + 8 * g);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc[nt][r]: row = (r&3) + 8*(r>>2) + 4*lh, col = lr   (C/D map of the 32x32 MFMA)
+  const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE || p.store == STORE_NCHW;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    int m = m0 + row;
+    if (m >= M) continue;
+    int b = 0, y = 0, x = 0;
+    if (need_pos) {
+      b = m / HW;
+      int rem = m - b * HW;
+      y = rem / p.W;
+      x = rem - y * p.W;
+    }
+    bool keep = true;
+    if (p.epi_mask != MASK_NONE) {
+      bool lowp = is_low_freq(y, x, p.H, p.W, p.bs, p.low);
+      keep = (p.epi_mask == MASK_LOW) ? lowp : !lowp;
+    }
+    float rs = p.rowscale ? p.rowscale[b] : 1.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      int n = n0 + nt * 32 + lr;
+      if (n >= p.Cout) continue;
+      float v = acc[nt][r];
+      if (p.bias) v += p.bias[n];
+      if (p.tb) v += p.tb[(size_t)b * p.ldtb + n];
+      v = act_apply(v, p.epi_act);
+      if (p.mul) v *= p.mul[(size_t)m * p.ldmul + n];
+      if (p.rowscale) v *= rs;
+      if (!keep) v = 0.f;
+      if (p.res) v += p.res[(size_t)m * p.ldres + n];
+      if (p.store == STORE_NHWC) p.out[(size_t)m * p.ldo + n] = v;
+      else p.out[(((size_t)b * p.Cout + n) * p.H + y) * p.W + x] = v;
+    }
+  }
+}
+
+}  // namespace
+
+void launch_igemm(const IGemm& p, hipStream_t stream) {
+  if (p.Cin % 4 != 0 || p.lda % 4 != 0) throw std::runtime_error("igemm: Cin and lda must be multiples of 4");
+  if (p.taps != 1 && p.taps != 9) throw std::runtime_error("igemm: taps must be 1 or 9");
+  if (p.pro_mask != MASK_NONE && p.taps != 1) throw std::runtime_error("igemm: input mask needs taps == 1");
+  const int64_t M = (int64_t)p.B * p.H * p.W;
+  if (M <= 0 || p.Cout <= 0) return;
+  dim3 block(256);
+  if (p.Cout <= 32) {
+    dim3 grid((unsigned)cdiv64(M, BM), 1);
+    hipLaunchKernelGGL(igemm_kernel<1>, grid, block, 0, stream, p);
+  } else if (p.Cout <= 64) {
+    dim3 grid((unsigned)cdiv64(M, BM), 1);
+    hipLaunchKernelGGL(igemm_kernel<2>, grid, block, 0, stream, p);
+  } else {
+    dim3 grid((unsigned)cdiv64(M, BM), (unsigned)cdiv(p.Cout, 128));
+    hipLaunchKernelGGL(igemm_kernel<4>, grid, block, 0, stream, p);
+  }
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace ddpmir

@@ -1,0 +1,109 @@
+// Launch wrappers of every HIP kernel on the restoration hot path (gfx950).  All tensors are fp32 NHWC
+// with an explicit pixel-row stride (ld, in floats) so a block can write straight into a channel slice of
+// a concat buffer.  Every launcher is asynchronous on `stream` and allocation-free (graph-capturable).
+#pragma once
+#include "common.h"
+
+namespace ddpmir {
+
+// ------------------------------------------------------------------------------------------------ igemm
+// out[m][n] = epilogue( sum_{tap,c} prologue(A[pix(m)+tap][c]) * Wt[tap][n][c] )
+// Covers nn.Conv2d 3x3 pad 1 (taps=9), 1x1 conv / nn.Linear (taps=1).  Reference: a3/a4/a6/a8 of SURVEY 8(a).
+struct IGemm {
+  // input
+  const float* A = nullptr; int lda = 0;      // [B*H*W][lda], channels 0..Cin-1 used (Cin % 4 == 0)
+  int B = 1, H = 1, W = 1, Cin = 0;
+  // weights, packed [taps][Cout][Cin]
+  const float* Wt = nullptr; int Cout = 0; int taps = 1;
+  const float* bias = nullptr;                // [Cout] or null
+  // prologue: v = A*scale[b][c] + shift[b][c]; act; static frequency mask on the pixel position
+  const float* scale = nullptr; const float* shift = nullptr;   // [B][Cin] or null
+  int pro_act = ACT_NONE;
+  int pro_mask = MASK_NONE; int bs = 4, low = 3;
+  // epilogue: v = act(acc + bias + tb[b][n]); v *= mul[m][n]; v *= rowscale[b]; v = mask? v:0; v += res[m][n]
+  const float* tb = nullptr; int ldtb = 0;
+  int epi_act = ACT_NONE;
+  const float* mul = nullptr; int ldmul = 0;
+  const float* rowscale = nullptr;            // [B]
+  int epi_mask = MASK_NONE;
+  const float* res = nullptr; int ldres = 0;
+  // output
+  float* out = nullptr; int ldo = 0; int store = STORE_NHWC;
+};
+void launch_igemm(const IGemm& p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------ attention
+// softmax(Q K^T / sqrt(d)) V per (batch, head); qkv is [B][N][3C] (q | k | v, heads contiguous in C),
+// out is [B][N][ldo] (first C columns).  Reference: nn.MultiheadAttention core, webp_inference.py:319.
+void launch_attention(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------ pointwise
+// GroupNorm statistics -> per-(b,c) scale/shift so that norm(x) = x*scale + shift (eps 1e-5, biased var).
+// `partial` is scratch of >= B*G*gn_splits(...)*2 doubles.
+int gn_splits(int HW, int C);
+void launch_gn_scale_shift(const float* x, int ldx, int B, int HW, int C, int G, const float* gamma,
+                           const float* beta, double* partial, float* scale, float* shift, hipStream_t stream);
+
+void launch_maxpool2(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, hipStream_t s);
+void launch_upsample2(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, hipStream_t s);
+// generic bilinear resize (align_corners=False, coordinate scale = in/out) -- AVIF pooled gates
+void launch_bilinear(const float* in, int ldi, float* out, int ldo, int B, int Hi, int Wi, int Ho, int Wo,
+                     int C, float scale_h, float scale_w, int accumulate, float out_scale, hipStream_t s);
+void launch_adaptive_avgpool(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int S,
+                             hipStream_t s);
+
+// blockwise Y = T X T^T (block bs in {4,8}); mats: one [bs][bs] matrix (per_channel=0) or [C][bs][bs].
+// out = mix_in * x + mix_t * Y   (mix_in=0,mix_t=1: plain transform; head: 1, 0.1)
+void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int bs,
+                            const float* mats, int per_channel, float mix_in, float mix_t, hipStream_t s);
+
+// out = a * b * c * d (+ base)   elementwise over [M][C] with per-tensor strides; null pointers are skipped
+void launch_mul4_add(const float* base, int ldb, const float* a, int lda, const float* b, int ldb2, const float* c,
+                     int ldc, const float* d, int ldd, float* out, int ldo, int64_t M, int C, hipStream_t s);
+
+// time embedding (webp_inference.py:145-151) + all per-block time projections (webp_inference.py:308)
+struct TimeEmbedW {
+  const float* w0; const float* b0;   // [1024][256], [1024]
+  const float* w2; const float* b2;   // [256][1024], [256]
+  const float* wt; const float* bt;   // concatenated time_proj: [NT][256], [NT]
+  int NT;
+};
+void launch_time_embed(const float* t, int B, const TimeEmbedW& w, float* hidden, float* temb, float* tproj,
+                       hipStream_t s);
+
+// boost[b] = clamp(a0 + a1*(1 - cl[b]), lo, hi)
+void launch_cl_boost(const float* cl, int B, float a0, float a1, float lo, float hi, float* out, hipStream_t s);
+
+// layout changes for the 3-channel image at the boundary
+void launch_nchw3_to_nhwc4(const float* in, float* out, int B, int H, int W, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------ sampler
+// u8 = uint8(trunc(clamp(x*127.5+127.5, 0, 255)))  (two roundings, no fma)   webp_inference.py:509
+void launch_quantize_u8(const float* x, uint8_t* u8, int64_t n, hipStream_t s);
+// DDRM update (webp_inference.py:584-600); dec_u8 is the decoded codec output.  noise may be null (i==0).
+void launch_ddrm_update(const float* x_theta, const uint8_t* dec_u8, const float* y, const float* noise,
+                        float* x_out, int64_t n_per_image, int B, float eta, float eta_b, float one_minus_eta_b,
+                        float noise_coeff, int step_i, int steps, int last, hipStream_t s);
+void launch_fill_t(float* t, int B, int step_i, int steps, hipStream_t s);
+// Philox4x32-10 + Box-Muller standard normal, counter = global element index (independent of GPU count)
+void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s);
+
+// phase_consistency (webp_inference.py:531-550) on NCHW planes via separable DFTs.
+struct DftPlan {           // device twiddle tables
+  const float* cos_h; const float* sin_h; int H;
+  const float* cos_w; const float* sin_w; int W;
+};
+// forward 2-D DFT of `planes` real images [P][H][W] -> re/im [P][H][W]; tmp_* are [P][H][W] scratch
+void launch_dft2_forward(const float* x, float* re, float* im, float* tmp_re, float* tmp_im, int P,
+                         const DftPlan& d, hipStream_t s);
+// unit phase of the reference spectrum: (re,im)/|.|, (1,0) where |.|==0
+void launch_unit_phase(float* re, float* im, int64_t n, hipStream_t s);
+// out = alpha*x + (1-alpha) * Re(ifft2(|X| * U))   (X = re/im in, U = unit phase)
+void launch_phase_apply_inverse(const float* x, const float* xre, const float* xim, const float* ure,
+                                const float* uim, float* tmp_re, float* tmp_im, float* tmp2_re, float* tmp2_im,
+                                float* out, int P, const DftPlan& d, float alpha, hipStream_t s);
+
+// eps-DDPM posterior mean step (conv.ipynb c1:124): x = c1 * (x - c2 * eps)
+void launch_axpby(const float* x, const float* e, float* out, float c1, float c2, int64_t n, hipStream_t s);
+
+}  // namespace ddpmir

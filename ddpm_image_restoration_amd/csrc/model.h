@@ -1,0 +1,144 @@
+// Host-side model of the restoration U-Nets: packed weights, workspace plan, forward, sampling loops.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ddpmir.h"
+#include "kernels.h"
+
+namespace ddpmir {
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+// bump allocator over one device allocation; dry run (base == nullptr) only measures
+struct Arena {
+  char* base = nullptr;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct ConvW {          // packed [taps][Cout][CinP] + bias
+  float* w = nullptr; float* b = nullptr;
+  int cout = 0, cin = 0, cinp = 0, taps = 1;
+};
+
+struct AvifTransformW {
+  float* tw = nullptr;  // [C][8][8]
+  ConvW q0, q2;
+};
+
+struct BlockW {
+  std::string name;
+  int cin = 0, cinp = 0, cout = 0, level = 0;
+  bool has_shortcut = false;
+  float *n1g = nullptr, *n1b = nullptr, *n2g = nullptr, *n2b = nullptr;
+  ConvW conv1, conv2, in_proj, out_proj, shortcut, conv_out;
+  int tproj_off = 0;
+  // WebP / JPEG frequency block
+  float* dct = nullptr;
+  ConvW low0, low2, high0, high2;
+  // AVIF frequency block
+  AvifTransformW at;
+  ConvW ms1[4], ms3[4], cc0, cc2, ep0, ep2;
+};
+
+struct ArchConsts {
+  int heads, dct_block, low_size;
+  float boost_lo, boost_hi, head_mix, noise_coeff;
+  int phase_q, phase_every;
+  double phase_alpha;
+};
+
+class Context {
+ public:
+  explicit Context(const ddpmir_config& cfg);
+  ~Context();
+
+  std::string err;
+  ddpmir_config cfg;
+  ArchConsts k;
+
+  void load_tensor(const std::string& name, const float* data, const int64_t* shape, int ndim);
+  size_t weight_blob_bytes();
+  void finalize_weights(void* dev_blob, int fill);
+  int64_t param_count() const { return n_params_; }
+
+  void predict(const float* x, const float* t, const float* cl, float* out, int B, int H, int W, hipStream_t s);
+  void ddrm_sample_loop(const float* y, float* out, int B, int H, int W, int quality, int steps, float eta,
+                        float eta_b, const ddpmir_loop_opts* opts);
+  void phase_consistency(const float* x, const float* ref, float* out, int B, int H, int W, float alpha);
+  float last_forward_ms = 0.f;
+
+ private:
+  // ---- weights
+  std::map<std::string, HostTensor> host_;
+  std::vector<BlockW> blocks_;
+  TimeEmbedW tw_{};
+  float *head_g_ = nullptr, *head_b_ = nullptr, *head_dct_ = nullptr;
+  AvifTransformW head_at_;
+  ConvW head_conv_;
+  char* wblob_ = nullptr;
+  bool wblob_owned_ = false;
+  bool finalized_ = false;
+  int64_t n_params_ = 0;
+  int nt_total_ = 0;
+  void layout_weights(Arena& a, bool upload);
+  void put(Arena& a, bool upload, float*& dst, const std::string& name, size_t expect);
+  void put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name, int cout, int cin, int ksz);
+
+  // ---- workspace (planned per (B,H,W))
+  struct Plan {
+    int B = 0, H = 0, W = 0;
+    char* base = nullptr; size_t bytes = 0;
+    float* x4 = nullptr;
+    float* cat[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // concat inputs of up5..up1, index = level
+    float* pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // pooled inputs, index = level (1..5)
+    float *bb0 = nullptr, *bb1 = nullptr, *bb2 = nullptr;
+    float* u[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // outputs of up blocks, index = level
+    float *hA = nullptr, *hB = nullptr, *qkv = nullptr, *att = nullptr, *xd = nullptr, *hid = nullptr, *S = nullptr;
+    float *xt = nullptr, *avg = nullptr, *col = nullptr, *edge = nullptr, *pool = nullptr, *pg1 = nullptr, *pg2 = nullptr;
+    double* gn_partial = nullptr;
+    float *sc1 = nullptr, *sh1 = nullptr, *sc2 = nullptr, *sh2 = nullptr;
+    float *hidden = nullptr, *temb = nullptr, *tproj = nullptr;
+    float *boost = nullptr, *boost2 = nullptr, *constmix = nullptr;
+    // sampler state
+    float *s_xt = nullptr, *s_theta = nullptr, *s_y = nullptr, *s_noise = nullptr, *s_t = nullptr;
+    uint8_t *s_u8 = nullptr, *s_dec = nullptr;
+    float* dft[10] = {nullptr};
+    float *tw_ch = nullptr, *tw_sh = nullptr, *tw_cw = nullptr, *tw_sw = nullptr;
+    // graph
+    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+    float *g_x = nullptr, *g_t = nullptr, *g_cl = nullptr, *g_out = nullptr;
+  } plan_;
+  void ensure_plan(int B, int H, int W);
+  void layout_plan(Arena& a, int B, int H, int W);
+  void free_plan();
+
+  void forward(const float* x, const float* t, const float* cl, float* out, hipStream_t s);
+  void run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
+  void freq_dct(const BlockW& bw, int H, int W, hipStream_t s);
+  void freq_avif(const BlockW& bw, int H, int W, hipStream_t s);
+  void avif_transform(const AvifTransformW& at, const float* x, int ldx, int C, int H, int W, float* T, float* tmp,
+                      float* out, int ldo, const float* rowscale, const float* res, int ldres, hipStream_t s);
+  void conv(const ConvW& cw, IGemm p, hipStream_t s);
+  void phase_fix(float* x, int B, int H, int W, double alpha, hipStream_t s);   // uses cached unit phase of y
+  void phase_prepare(const float* y, int B, int H, int W, hipStream_t s);
+
+  hipStream_t stream_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  uint8_t *pin_in_ = nullptr, *pin_out_ = nullptr; size_t pin_bytes_ = 0;
+};
+
+}  // namespace ddpmir

@@ -1,0 +1,580 @@
+// Host orchestration of the restoration U-Net forward and the DDRM sampling loop on one MI355X.
+// Reference structure: webp_inference.py:303-327 (block), :369-399 (U-Net), :557-602 (sampler).
+#include "model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+namespace ddpmir {
+
+namespace {
+
+struct BlockDef { const char* name; int cin, cout, level; };
+// webp_inference.py:337-356
+const BlockDef kBlocks[13] = {
+    {"down1", 3, 64, 0},          {"down2", 64, 128, 1},         {"down3", 128, 256, 2},
+    {"down4", 256, 512, 3},       {"down5", 512, 512, 4},        {"bottleneck.0", 512, 1024, 5},
+    {"bottleneck.1", 1024, 1024, 5}, {"bottleneck.2", 1024, 512, 5}, {"up1", 1024, 512, 4},
+    {"up2", 1024, 256, 3},        {"up3", 512, 128, 2},          {"up4", 256, 64, 1},
+    {"up5", 128, 64, 0}};
+
+int gn_groups(int c) {  // webp_inference.py:277-279
+  int g = std::min(8, c);
+  while (c % g != 0 && g > 1) --g;
+  return g;
+}
+
+ArchConsts consts_for(int arch) {
+  switch (arch) {
+    case DDPMIR_ARCH_WEBP: return {4, 4, 3, 0.15f, 1.9f, 0.1f, 0.2f, 15, 5, 0.7};
+    case DDPMIR_ARCH_JPEG: return {4, 8, 4, 0.2f, 2.0f, 0.1f, 0.2f, 20, 5, 0.7};
+    case DDPMIR_ARCH_AVIF: return {8, 8, 0, 0.f, 0.f, 0.15f, 0.15f, 30, 3, 0.8};
+    default: throw std::runtime_error("unknown arch");
+  }
+}
+
+}  // namespace
+
+Context::Context(const ddpmir_config& c) : cfg(c), k(consts_for(c.arch)) {
+  if (cfg.dtype != DDPMIR_F32) throw std::runtime_error("dtype: only DDPMIR_F32 is built in this version");
+  DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
+  DDPMIR_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  DDPMIR_HIP_CHECK(hipEventCreate(&ev0_));
+  DDPMIR_HIP_CHECK(hipEventCreate(&ev1_));
+}
+
+Context::~Context() {
+  (void)hipSetDevice(cfg.device);
+  free_plan();
+  if (wblob_ && wblob_owned_) (void)hipFree(wblob_);
+  if (pin_in_) (void)hipHostFree(pin_in_);
+  if (pin_out_) (void)hipHostFree(pin_out_);
+  if (ev0_) (void)hipEventDestroy(ev0_);
+  if (ev1_) (void)hipEventDestroy(ev1_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+void Context::load_tensor(const std::string& name, const float* data, const int64_t* shape, int ndim) {
+  if (finalized_) throw std::runtime_error("load_tensor after finalize_weights");
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.assign(data, data + t.numel());
+  host_[name] = std::move(t);
+}
+
+void Context::put(Arena& a, bool upload, float*& dst, const std::string& name, size_t expect) {
+  dst = a.take<float>(expect);
+  if (name.find("dct_matrix") == std::string::npos) n_params_ += (int64_t)expect;
+  if (!upload) return;
+  auto it = host_.find(name);
+  if (it == host_.end()) throw std::runtime_error("missing tensor in state dict: " + name);
+  if ((size_t)it->second.numel() != expect)
+    throw std::runtime_error("shape mismatch for " + name + ": expected " + std::to_string(expect) + " elements, got " +
+                             std::to_string(it->second.numel()));
+  DDPMIR_HIP_CHECK(hipMemcpy(dst, it->second.data.data(), expect * sizeof(float), hipMemcpyHostToDevice));
+}
+
+// torch OIHW (or [out][in] for nn.Linear) -> [tap][Cout][CinP], CinP = Cin rounded up to 4 (zeros)
+void Context::put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name, int cout, int cin, int ksz) {
+  cw.cout = cout; cw.cin = cin; cw.cinp = round_up(cin, 4); cw.taps = ksz * ksz;
+  const size_t n = (size_t)cw.taps * cout * cw.cinp;
+  cw.w = a.take<float>(n);
+  cw.b = a.take<float>(cout);
+  n_params_ += (int64_t)cout * cin * cw.taps + cout;
+  if (!upload) return;
+  auto iw = host_.find(name + ".weight");
+  if (iw == host_.end()) iw = host_.find(name + "_weight");   // attn.in_proj_weight
+  auto ib = host_.find(name + ".bias");
+  if (ib == host_.end()) ib = host_.find(name + "_bias");
+  if (iw == host_.end() || ib == host_.end()) throw std::runtime_error("missing tensor in state dict: " + name);
+  if (iw->second.numel() != (int64_t)cout * cin * ksz * ksz || ib->second.numel() != cout)
+    throw std::runtime_error("shape mismatch for " + name);
+  std::vector<float> packed(n, 0.f);
+  const float* src = iw->second.data.data();
+  for (int o = 0; o < cout; ++o)
+    for (int c = 0; c < cin; ++c)
+      for (int t = 0; t < cw.taps; ++t) packed[((size_t)t * cout + o) * cw.cinp + c] = src[((size_t)o * cin + c) * cw.taps + t];
+  DDPMIR_HIP_CHECK(hipMemcpy(cw.w, packed.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  DDPMIR_HIP_CHECK(hipMemcpy(cw.b, ib->second.data.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+}
+
+void Context::layout_weights(Arena& a, bool up) {
+  n_params_ = 0;
+  blocks_.assign(13, BlockW());
+  float *w0, *b0, *w2, *b2;
+  put(a, up, w0, "time_embed.proj.0.weight", 1024 * 256);
+  put(a, up, b0, "time_embed.proj.0.bias", 1024);
+  put(a, up, w2, "time_embed.proj.2.weight", 256 * 1024);
+  put(a, up, b2, "time_embed.proj.2.bias", 256);
+  nt_total_ = 0;
+  for (auto& d : kBlocks) nt_total_ += d.cout;
+  float* wt = a.take<float>((size_t)nt_total_ * 256);
+  float* bt = a.take<float>(nt_total_);
+  tw_ = TimeEmbedW{w0, b0, w2, b2, wt, bt, nt_total_};
+  int off = 0;
+  const bool avif = cfg.arch == DDPMIR_ARCH_AVIF;
+  for (int i = 0; i < 13; ++i) {
+    const BlockDef& d = kBlocks[i];
+    BlockW& b = blocks_[i];
+    const std::string n = d.name;
+    b.name = n; b.cin = d.cin; b.cinp = round_up(d.cin, 4); b.cout = d.cout; b.level = d.level;
+    b.has_shortcut = d.cin != d.cout;
+    b.tproj_off = off;
+    put(a, up, b.n1g, n + ".norm1.weight", d.cin);
+    put(a, up, b.n1b, n + ".norm1.bias", d.cin);
+    put_conv(a, up, b.conv1, n + ".conv1", d.cout, d.cin, 3);
+    if (up) {
+      auto iw = host_.find(n + ".time_proj.weight"), ib = host_.find(n + ".time_proj.bias");
+      if (iw == host_.end() || ib == host_.end()) throw std::runtime_error("missing tensor in state dict: " + n + ".time_proj");
+      if (iw->second.numel() != (int64_t)d.cout * 256 || ib->second.numel() != d.cout)
+        throw std::runtime_error("shape mismatch for " + n + ".time_proj");
+      DDPMIR_HIP_CHECK(hipMemcpy(wt + (size_t)off * 256, iw->second.data.data(), (size_t)d.cout * 256 * 4, hipMemcpyHostToDevice));
+      DDPMIR_HIP_CHECK(hipMemcpy(bt + off, ib->second.data.data(), (size_t)d.cout * 4, hipMemcpyHostToDevice));
+    }
+    n_params_ += (int64_t)d.cout * 257;
+    off += d.cout;
+    put(a, up, b.n2g, n + ".norm2.weight", d.cout);
+    put(a, up, b.n2b, n + ".norm2.bias", d.cout);
+    put_conv(a, up, b.conv2, n + ".conv2", d.cout, d.cout, 3);
+    put_conv(a, up, b.in_proj, n + ".attn.in_proj", 3 * d.cout, d.cout, 1);
+    put_conv(a, up, b.out_proj, n + ".attn.out_proj", d.cout, d.cout, 1);
+    const std::string fg = n + ".freq_guide";
+    if (avif) {
+      put(a, up, b.at.tw, fg + ".adaptive_transform.transform_weights", (size_t)d.cout * 64);
+      // inverse_weights is a parameter the forward never reads (avif_inference.py:130): validated and counted only
+      if (up && host_.find(fg + ".adaptive_transform.inverse_weights") == host_.end())
+        throw std::runtime_error("missing tensor in state dict: " + fg + ".adaptive_transform.inverse_weights");
+      n_params_ += (int64_t)d.cout * 64;
+      put_conv(a, up, b.at.q0, fg + ".adaptive_transform.quantization.0", d.cout, d.cout, 1);
+      put_conv(a, up, b.at.q2, fg + ".adaptive_transform.quantization.2", d.cout, d.cout, 1);
+      for (int s = 0; s < 4; ++s) {
+        put_conv(a, up, b.ms1[s], fg + ".multi_scale_attn." + std::to_string(s) + ".1", d.cout / 4, d.cout, 1);
+        put_conv(a, up, b.ms3[s], fg + ".multi_scale_attn." + std::to_string(s) + ".3", d.cout, d.cout / 4, 1);
+      }
+      put_conv(a, up, b.cc0, fg + ".color_consistency.0", d.cout, d.cout, 1);
+      put_conv(a, up, b.cc2, fg + ".color_consistency.2", d.cout, d.cout, 1);
+      put_conv(a, up, b.ep0, fg + ".edge_preserve.0", d.cout / 2, d.cout, 3);
+      put_conv(a, up, b.ep2, fg + ".edge_preserve.2", d.cout, d.cout / 2, 3);
+    } else {
+      put(a, up, b.dct, fg + ".dct.dct_matrix", (size_t)k.dct_block * k.dct_block);
+      put_conv(a, up, b.low0, fg + ".low_freq_attn.0", d.cout / 2, d.cout, 1);
+      put_conv(a, up, b.low2, fg + ".low_freq_attn.2", d.cout, d.cout / 2, 1);
+      put_conv(a, up, b.high0, fg + ".high_freq_attn.0", d.cout / 2, d.cout, 1);
+      put_conv(a, up, b.high2, fg + ".high_freq_attn.2", d.cout, d.cout / 2, 1);
+    }
+    put_conv(a, up, b.conv_out, fg + ".conv_out", d.cout, d.cout, 3);
+    if (b.has_shortcut) put_conv(a, up, b.shortcut, n + ".shortcut", d.cout, d.cin, 1);
+  }
+  if (avif) {
+    put(a, up, head_at_.tw, "avif_layer.transform_weights", 64 * 64);
+    if (up && host_.find("avif_layer.inverse_weights") == host_.end())
+      throw std::runtime_error("missing tensor in state dict: avif_layer.inverse_weights");
+    n_params_ += 64 * 64;
+    put_conv(a, up, head_at_.q0, "avif_layer.quantization.0", 64, 64, 1);
+    put_conv(a, up, head_at_.q2, "avif_layer.quantization.2", 64, 64, 1);
+  } else {
+    put(a, up, head_dct_, "dct_layer.dct_matrix", (size_t)k.dct_block * k.dct_block);
+  }
+  put(a, up, head_g_, "out_conv.0.weight", 64);
+  put(a, up, head_b_, "out_conv.0.bias", 64);
+  put_conv(a, up, head_conv_, "out_conv.2", 3, 64, 3);
+}
+
+size_t Context::weight_blob_bytes() {
+  Arena a;
+  layout_weights(a, false);
+  return (a.off + 255) & ~size_t(255);
+}
+
+void Context::finalize_weights(void* dev_blob, int fill) {
+  DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
+  const size_t bytes = weight_blob_bytes();
+  if (dev_blob) {
+    wblob_ = static_cast<char*>(dev_blob);
+    wblob_owned_ = false;
+  } else {
+    DDPMIR_HIP_CHECK(hipMalloc(&wblob_, bytes));
+    wblob_owned_ = true;
+    fill = 1;
+  }
+  Arena a;
+  a.base = wblob_;
+  if (fill) DDPMIR_HIP_CHECK(hipMemset(wblob_, 0, bytes));
+  layout_weights(a, fill != 0);
+  DDPMIR_HIP_CHECK(hipDeviceSynchronize());
+  host_.clear();
+  finalized_ = true;
+}
+
+// ------------------------------------------------------------------------------------------------ workspace
+void Context::layout_plan(Arena& a, int B, int H, int W) {
+  Plan& p = plan_;
+  const bool avif = cfg.arch == DDPMIR_ARCH_AVIF;
+  auto hw = [&](int lvl) { return (size_t)(H >> lvl) * (W >> lvl); };
+  const size_t M0 = (size_t)B * H * W;
+  p.x4 = a.take<float>(M0 * 4);
+  const int cat_c[5] = {128, 256, 512, 1024, 1024};            // concat width at level 0..4
+  for (int l = 0; l < 5; ++l) p.cat[l] = a.take<float>((size_t)B * hw(l) * cat_c[l]);
+  const int pin_c[6] = {0, 64, 128, 256, 512, 512};            // pooled input channels at level 1..5
+  for (int l = 1; l <= 5; ++l) p.pin[l] = a.take<float>((size_t)B * hw(l) * pin_c[l]);
+  p.bb0 = a.take<float>((size_t)B * hw(5) * 1024);
+  p.bb1 = a.take<float>((size_t)B * hw(5) * 1024);
+  p.bb2 = a.take<float>((size_t)B * hw(5) * 512);
+  const int u_c[5] = {64, 64, 128, 256, 512};                  // up-block output channels at level 0..4
+  for (int l = 0; l < 5; ++l) p.u[l] = a.take<float>((size_t)B * hw(l) * u_c[l]);
+  // per-block scratch: max over blocks of pixels*cout is at level 0 (64 ch); deeper levels never exceed it
+  size_t mc = 0;
+  for (auto& d : kBlocks) mc = std::max(mc, (size_t)B * hw(d.level) * d.cout);
+  p.hA = a.take<float>(mc); p.hB = a.take<float>(mc); p.att = a.take<float>(mc);
+  p.xd = a.take<float>(mc); p.S = a.take<float>(mc); p.hid = a.take<float>(mc);
+  p.qkv = a.take<float>(mc * 3);
+  if (avif) {
+    p.xt = a.take<float>(mc); p.avg = a.take<float>(mc); p.col = a.take<float>(mc); p.edge = a.take<float>(mc);
+    p.pool = a.take<float>((size_t)B * 64 * 1024); p.pg1 = a.take<float>((size_t)B * 64 * 256);
+    p.pg2 = a.take<float>((size_t)B * 64 * 1024);
+  }
+  int max_splits = gn_splits(H * W, 64);
+  p.gn_partial = a.take<double>((size_t)B * 8 * max_splits * 2 + 64);
+  p.sc1 = a.take<float>((size_t)B * 1024); p.sh1 = a.take<float>((size_t)B * 1024);
+  p.sc2 = a.take<float>((size_t)B * 1024); p.sh2 = a.take<float>((size_t)B * 1024);
+  p.hidden = a.take<float>((size_t)B * 1024); p.temb = a.take<float>((size_t)B * 256);
+  p.tproj = a.take<float>((size_t)B * nt_total_);
+  p.boost = a.take<float>(B); p.boost2 = a.take<float>(B); p.constmix = a.take<float>(B);
+  // sampler
+  const size_t n_img = (size_t)B * 3 * H * W;
+  p.s_xt = a.take<float>(n_img); p.s_theta = a.take<float>(n_img); p.s_y = a.take<float>(n_img);
+  p.s_noise = a.take<float>(n_img + 4); p.s_t = a.take<float>(B);
+  p.s_u8 = a.take<uint8_t>(n_img); p.s_dec = a.take<uint8_t>(n_img);
+  for (int i = 0; i < 10; ++i) p.dft[i] = a.take<float>(n_img);
+  p.tw_ch = a.take<float>(H); p.tw_sh = a.take<float>(H); p.tw_cw = a.take<float>(W); p.tw_sw = a.take<float>(W);
+  p.g_x = a.take<float>(n_img); p.g_out = a.take<float>(n_img); p.g_t = a.take<float>(B); p.g_cl = a.take<float>(B);
+}
+
+void Context::free_plan() {
+  if (plan_.gexec) (void)hipGraphExecDestroy(plan_.gexec);
+  if (plan_.graph) (void)hipGraphDestroy(plan_.graph);
+  if (plan_.base) (void)hipFree(plan_.base);
+  plan_ = Plan();
+}
+
+void Context::ensure_plan(int B, int H, int W) {
+  if (plan_.base && plan_.B == B && plan_.H == H && plan_.W == W) return;
+  if (B <= 0 || H <= 0 || W <= 0 || (H % 32) != 0 || (W % 32) != 0)
+    throw std::invalid_argument("image size must be a positive multiple of 32 (five 2x2 pools)");
+  DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
+  free_plan();
+  Arena dry;
+  layout_plan(dry, B, H, W);
+  size_t bytes = (dry.off + 255) & ~size_t(255);
+  char* base = nullptr;
+  DDPMIR_HIP_CHECK(hipMalloc(&base, bytes));
+  DDPMIR_HIP_CHECK(hipMemset(base, 0, bytes));
+  Arena a; a.base = base;
+  layout_plan(a, B, H, W);
+  plan_.base = base; plan_.bytes = bytes; plan_.B = B; plan_.H = H; plan_.W = W;
+  // DFT twiddles (double precision on the host, rounded once)
+  auto tw = [&](int n, float* dc, float* ds) {
+    std::vector<float> c(n), s(n);
+    for (int i = 0; i < n; ++i) {
+      double ang = 2.0 * M_PI * (double)i / (double)n;
+      c[i] = (float)std::cos(ang); s[i] = (float)std::sin(ang);
+    }
+    DDPMIR_HIP_CHECK(hipMemcpy(dc, c.data(), n * 4, hipMemcpyHostToDevice));
+    DDPMIR_HIP_CHECK(hipMemcpy(ds, s.data(), n * 4, hipMemcpyHostToDevice));
+  };
+  tw(H, plan_.tw_ch, plan_.tw_sh);
+  tw(W, plan_.tw_cw, plan_.tw_sw);
+  std::vector<float> mix(B, k.head_mix);
+  DDPMIR_HIP_CHECK(hipMemcpy(plan_.constmix, mix.data(), B * 4, hipMemcpyHostToDevice));
+  size_t need = (size_t)B * 3 * H * W;
+  if (need > pin_bytes_) {
+    if (pin_in_) (void)hipHostFree(pin_in_);
+    if (pin_out_) (void)hipHostFree(pin_out_);
+    DDPMIR_HIP_CHECK(hipHostMalloc(&pin_in_, need));
+    DDPMIR_HIP_CHECK(hipHostMalloc(&pin_out_, need));
+    pin_bytes_ = need;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+void Context::conv(const ConvW& cw, IGemm p, hipStream_t s) {
+  p.Wt = cw.w; p.bias = cw.b; p.Cout = cw.cout; p.Cin = cw.cinp; p.taps = cw.taps;
+  launch_igemm(p, s);
+}
+
+// WebP/JPEG frequency block (webp_inference.py:231-270).  In: plan_.hB.  Out: plan_.S = x + ga*low + gb*high.
+void Context::freq_dct(const BlockW& bw, int H, int W, hipStream_t s) {
+  Plan& p = plan_;
+  const int B = p.B, C = bw.cout;
+  launch_block_transform(p.hB, C, p.xd, C, B, H, W, C, k.dct_block, bw.dct, 0, 0.f, 1.f, s);
+  IGemm g;
+  g.B = B; g.H = H; g.W = W; g.bs = k.dct_block; g.low = k.low_size;
+  // low gate: hid = lrelu(W1 (xd*Mlow) + b1); S = hB + sigmoid(W2 hid + b2) * xd * Mlow
+  IGemm a = g; a.A = p.xd; a.lda = C; a.pro_mask = MASK_LOW; a.epi_act = ACT_LRELU; a.out = p.hid; a.ldo = C / 2;
+  conv(bw.low0, a, s);
+  IGemm b2 = g; b2.A = p.hid; b2.lda = C / 2; b2.epi_act = ACT_SIGMOID; b2.mul = p.xd; b2.ldmul = C;
+  b2.epi_mask = MASK_LOW; b2.res = p.hB; b2.ldres = C; b2.out = p.S; b2.ldo = C;
+  conv(bw.low2, b2, s);
+  // high gate (boosted by clamp(1-cl)) accumulates in place
+  IGemm c = a; c.pro_mask = MASK_HIGH;
+  conv(bw.high0, c, s);
+  IGemm d = b2; d.epi_mask = MASK_HIGH; d.rowscale = p.boost; d.res = p.S; d.out = p.S;
+  conv(bw.high2, d, s);
+}
+
+// AVIFAdaptiveTransform (avif_inference.py:140-182): out = rowscale * (T * sigmoid(q2(relu(q0(T))))) + res
+void Context::avif_transform(const AvifTransformW& at, const float* x, int ldx, int C, int H, int W, float* T,
+                             float* tmp, float* out, int ldo, const float* rowscale, const float* res, int ldres,
+                             hipStream_t s) {
+  const int B = plan_.B;
+  launch_block_transform(x, ldx, T, C, B, H, W, C, 8, at.tw, 1, 0.f, 1.f, s);
+  IGemm g; g.B = B; g.H = H; g.W = W;
+  IGemm a = g; a.A = T; a.lda = C; a.epi_act = ACT_RELU; a.out = tmp; a.ldo = C;
+  conv(at.q0, a, s);
+  IGemm b = g; b.A = tmp; b.lda = C; b.epi_act = ACT_SIGMOID; b.mul = T; b.ldmul = C; b.rowscale = rowscale;
+  b.res = res; b.ldres = ldres; b.out = out; b.ldo = ldo;
+  conv(at.q2, b, s);
+}
+
+// AVIF frequency block (avif_inference.py:222-256).  In: plan_.hB.  Out: plan_.S = x + xt*avg*color*edge.
+void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
+  Plan& p = plan_;
+  const int B = p.B, C = bw.cout;
+  const int64_t M = (int64_t)B * H * W;
+  avif_transform(bw.at, p.hB, C, C, H, W, p.xd, p.hid, p.xt, C, nullptr, nullptr, 0, s);
+  const int scales[4] = {1, 2, 4, 8};
+  for (int i = 0; i < 4; ++i) {
+    const int S = scales[i];
+    launch_adaptive_avgpool(p.hB, C, p.pool, C, B, H, W, C, S, s);
+    IGemm g; g.B = B; g.H = S; g.W = S;
+    IGemm a = g; a.A = p.pool; a.lda = C; a.epi_act = ACT_RELU; a.out = p.pg1; a.ldo = C / 4;
+    conv(bw.ms1[i], a, s);
+    IGemm b = g; b.A = p.pg1; b.lda = C / 4; b.epi_act = ACT_SIGMOID; b.out = p.pg2; b.ldo = C;
+    conv(bw.ms3[i], b, s);
+    // F.interpolate(size=x.shape[-2:]) -> coordinate scale in/out; identical sizes reduce to a copy
+    launch_bilinear(p.pg2, C, p.avg, C, B, S, S, H, W, C, (float)S / (float)H, (float)S / (float)W, i > 0 ? 1 : 0,
+                    i == 3 ? 0.25f : 1.0f, s);
+  }
+  IGemm g; g.B = B; g.H = H; g.W = W;
+  IGemm c0 = g; c0.A = p.hB; c0.lda = C; c0.epi_act = ACT_RELU; c0.out = p.hid; c0.ldo = C;
+  conv(bw.cc0, c0, s);
+  IGemm c2 = g; c2.A = p.hid; c2.lda = C; c2.epi_act = ACT_SIGMOID; c2.rowscale = p.boost; c2.out = p.col; c2.ldo = C;
+  conv(bw.cc2, c2, s);
+  IGemm e0 = g; e0.A = p.hB; e0.lda = C; e0.epi_act = ACT_RELU; e0.out = p.hid; e0.ldo = C / 2;
+  conv(bw.ep0, e0, s);
+  IGemm e2 = g; e2.A = p.hid; e2.lda = C / 2; e2.epi_act = ACT_SIGMOID; e2.rowscale = p.boost2; e2.out = p.edge; e2.ldo = C;
+  conv(bw.ep2, e2, s);
+  launch_mul4_add(p.hB, C, p.xt, C, p.avg, C, p.col, C, p.edge, C, p.S, C, M, C, s);
+}
+
+void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest,
+                        hipStream_t s) {
+  Plan& p = plan_;
+  const int B = p.B, C = bw.cout;
+  IGemm g; g.B = B; g.H = H; g.W = W;
+  // norm1 -> conv1 (+ bias + time projection)            webp_inference.py:304-309
+  launch_gn_scale_shift(in, ldin, B, H * W, bw.cin, gn_groups(bw.cin), bw.n1g, bw.n1b, p.gn_partial, p.sc1, p.sh1, s);
+  IGemm c1 = g; c1.A = in; c1.lda = ldin; c1.scale = p.sc1; c1.shift = p.sh1;
+  c1.tb = p.tproj + bw.tproj_off; c1.ldtb = nt_total_; c1.out = p.hA; c1.ldo = C;
+  conv(bw.conv1, c1, s);
+  // norm2 -> GELU -> conv2                               webp_inference.py:311-314
+  launch_gn_scale_shift(p.hA, C, B, H * W, C, gn_groups(C), bw.n2g, bw.n2b, p.gn_partial, p.sc2, p.sh2, s);
+  IGemm c2 = g; c2.A = p.hA; c2.lda = C; c2.scale = p.sc2; c2.shift = p.sh2; c2.pro_act = ACT_GELU;
+  c2.out = p.hB; c2.ldo = C;
+  conv(bw.conv2, c2, s);
+  // self-attention over all H*W tokens + residual        webp_inference.py:317-321
+  if (bw.level >= cfg.attn_min_level) {
+    IGemm q = g; q.A = p.hB; q.lda = C; q.out = p.qkv; q.ldo = 3 * C;
+    conv(bw.in_proj, q, s);
+    launch_attention(p.qkv, p.att, C, B, H * W, C, k.heads, s);
+    IGemm o = g; o.A = p.att; o.lda = C; o.res = p.hB; o.ldres = C; o.out = p.hB; o.ldo = C;
+    conv(bw.out_proj, o, s);
+  }
+  // frequency block -> S                                  webp_inference.py:324
+  if (cfg.arch == DDPMIR_ARCH_AVIF) freq_avif(bw, H, W, s);
+  else freq_dct(bw, H, W, s);
+  // shortcut + conv_out                                   webp_inference.py:270,327
+  const float* res = in; int ldres = ldin;
+  if (bw.has_shortcut) {
+    IGemm sc = g; sc.A = in; sc.lda = ldin; sc.out = dest; sc.ldo = lddest;
+    conv(bw.shortcut, sc, s);
+    res = dest; ldres = lddest;
+  }
+  IGemm co = g; co.A = p.S; co.lda = C; co.res = res; co.ldres = ldres; co.out = dest; co.ldo = lddest;
+  conv(bw.conv_out, co, s);
+}
+
+void Context::forward(const float* x, const float* t, const float* cl, float* out, hipStream_t s) {
+  Plan& p = plan_;
+  const int B = p.B, H = p.H, W = p.W;
+  launch_nchw3_to_nhwc4(x, p.x4, B, H, W, s);
+  launch_time_embed(t, B, tw_, p.hidden, p.temb, p.tproj, s);
+  if (cfg.arch == DDPMIR_ARCH_AVIF) {
+    launch_cl_boost(cl, B, 0.5f, 0.5f, 0.3f, 1.5f, p.boost, s);    // colour   avif_inference.py:246
+    launch_cl_boost(cl, B, 0.7f, 0.3f, 0.5f, 1.3f, p.boost2, s);   // edge     avif_inference.py:247
+  } else {
+    launch_cl_boost(cl, B, 0.f, 1.f, k.boost_lo, k.boost_hi, p.boost, s);   // webp_inference.py:263
+  }
+  auto hh = [&](int l) { return H >> l; };
+  auto ww = [&](int l) { return W >> l; };
+  // skip tensors are written straight into the second half of the matching up block's concat buffer
+  const int cat_c[5] = {128, 256, 512, 1024, 1024};
+  const int skip_off[5] = {64, 128, 256, 512, 512};
+  const int skip_c[5] = {64, 128, 256, 512, 512};
+  // down path
+  const float* in = p.x4; int ldin = 4;
+  for (int l = 0; l < 5; ++l) {
+    float* d = p.cat[l] + skip_off[l];
+    run_block(blocks_[l], in, ldin, hh(l), ww(l), d, cat_c[l], s);
+    launch_maxpool2(d, cat_c[l], p.pin[l + 1], skip_c[l], B, hh(l), ww(l), skip_c[l], s);
+    in = p.pin[l + 1]; ldin = skip_c[l];
+  }
+  run_block(blocks_[5], p.pin[5], 512, hh(5), ww(5), p.bb0, 1024, s);
+  run_block(blocks_[6], p.bb0, 1024, hh(5), ww(5), p.bb1, 1024, s);
+  run_block(blocks_[7], p.bb1, 1024, hh(5), ww(5), p.bb2, 512, s);
+  // up path: cat[upsampled, skip]                           webp_inference.py:389-393
+  const float* prev = p.bb2; int prev_c = 512;
+  for (int l = 4; l >= 0; --l) {
+    launch_upsample2(prev, prev_c, p.cat[l], cat_c[l], B, hh(l + 1), ww(l + 1), prev_c, s);
+    const BlockW& bw = blocks_[8 + (4 - l)];
+    run_block(bw, p.cat[l], cat_c[l], hh(l), ww(l), p.u[l], bw.cout, s);
+    prev = p.u[l]; prev_c = bw.cout;
+  }
+  // head: u5 + mix * transform(u5) -> GroupNorm(8) -> SiLU -> conv 64->3 -> tanh     webp_inference.py:396-399
+  if (cfg.arch == DDPMIR_ARCH_AVIF)
+    avif_transform(head_at_, p.u[0], 64, 64, H, W, p.xd, p.hid, p.S, 64, p.constmix, p.u[0], 64, s);
+  else
+    launch_block_transform(p.u[0], 64, p.S, 64, B, H, W, 64, k.dct_block, head_dct_, 0, 1.0f, k.head_mix, s);
+  launch_gn_scale_shift(p.S, 64, B, H * W, 64, 8, head_g_, head_b_, p.gn_partial, p.sc1, p.sh1, s);
+  IGemm hc; hc.B = B; hc.H = H; hc.W = W; hc.A = p.S; hc.lda = 64; hc.scale = p.sc1; hc.shift = p.sh1;
+  hc.pro_act = ACT_SILU; hc.epi_act = ACT_TANH; hc.out = out; hc.ldo = 0; hc.store = STORE_NCHW;
+  conv(head_conv_, hc, s);
+}
+
+void Context::predict(const float* x, const float* t, const float* cl, float* out, int B, int H, int W, hipStream_t s) {
+  if (!finalized_) throw std::logic_error("predict before finalize_weights");
+  DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
+  ensure_plan(B, H, W);
+  const bool own = (s == nullptr);
+  hipStream_t st = own ? stream_ : s;
+  Plan& p = plan_;
+  const size_t n_img = (size_t)B * 3 * H * W;
+  if (cfg.use_graph) {
+    // fixed-address staging buffers so the captured graph is replayable for any caller pointers
+    DDPMIR_HIP_CHECK(hipMemcpyAsync(p.g_x, x, n_img * 4, hipMemcpyDeviceToDevice, st));
+    DDPMIR_HIP_CHECK(hipMemcpyAsync(p.g_t, t, B * 4, hipMemcpyDeviceToDevice, st));
+    DDPMIR_HIP_CHECK(hipMemcpyAsync(p.g_cl, cl ? cl : t, B * 4, hipMemcpyDeviceToDevice, st));
+    if (!p.gexec) {
+      DDPMIR_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      try {
+        forward(p.g_x, p.g_t, p.g_cl, p.g_out, st);
+      } catch (...) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(st, &g);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+      }
+      DDPMIR_HIP_CHECK(hipStreamEndCapture(st, &p.graph));
+      DDPMIR_HIP_CHECK(hipGraphInstantiate(&p.gexec, p.graph, nullptr, nullptr, 0));
+    }
+    DDPMIR_HIP_CHECK(hipGraphLaunch(p.gexec, st));
+    DDPMIR_HIP_CHECK(hipMemcpyAsync(out, p.g_out, n_img * 4, hipMemcpyDeviceToDevice, st));
+  } else {
+    forward(x, t, cl ? cl : t, out, st);
+  }
+  if (own) DDPMIR_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+// ------------------------------------------------------------------------------------------------ phase fix
+void Context::phase_prepare(const float* y, int B, int H, int W, hipStream_t s) {
+  Plan& p = plan_;
+  DftPlan d{p.tw_ch, p.tw_sh, H, p.tw_cw, p.tw_sw, W};
+  const int P = B * 3;
+  // dft[0], dft[1] = unit phase of fft2(y)
+  launch_dft2_forward(y, p.dft[0], p.dft[1], p.dft[4], p.dft[5], P, d, s);
+  launch_unit_phase(p.dft[0], p.dft[1], (int64_t)P * H * W, s);
+}
+
+void Context::phase_fix(float* x, int B, int H, int W, double alpha, hipStream_t s) {
+  Plan& p = plan_;
+  DftPlan d{p.tw_ch, p.tw_sh, H, p.tw_cw, p.tw_sw, W};
+  const int P = B * 3;
+  launch_dft2_forward(x, p.dft[2], p.dft[3], p.dft[4], p.dft[5], P, d, s);
+  launch_phase_apply_inverse(x, p.dft[2], p.dft[3], p.dft[0], p.dft[1], p.dft[4], p.dft[5], p.dft[6], p.dft[7], x, P,
+                             d, (float)alpha, s);
+}
+
+void Context::phase_consistency(const float* x, const float* ref, float* out, int B, int H, int W, float alpha) {
+  DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
+  ensure_plan(B, H, W);
+  Plan& p = plan_;
+  const size_t n = (size_t)B * 3 * H * W;
+  phase_prepare(ref, B, H, W, stream_);
+  DDPMIR_HIP_CHECK(hipMemcpyAsync(p.dft[8], x, n * 4, hipMemcpyDeviceToDevice, stream_));
+  phase_fix(p.dft[8], B, H, W, alpha, stream_);
+  DDPMIR_HIP_CHECK(hipMemcpyAsync(out, p.dft[8], n * 4, hipMemcpyDeviceToDevice, stream_));
+  DDPMIR_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// ------------------------------------------------------------------------------------------------ DDRM loop
+void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, int quality, int steps, float eta,
+                               float eta_b, const ddpmir_loop_opts* opts) {
+  if (!finalized_) throw std::logic_error("sample before finalize_weights");
+  if (steps <= 0) throw std::invalid_argument("steps must be positive");
+  if (!opts || !opts->codec) throw std::invalid_argument("a codec callback is required (no built-in codec for this model family)");
+  DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
+  ensure_plan(B, H, W);
+  Plan& p = plan_;
+  hipStream_t s = stream_;
+  const size_t n = (size_t)B * 3 * H * W;
+  const float coeff = opts->noise_coeff >= 0.f ? opts->noise_coeff : k.noise_coeff;
+  const int phase_q = opts->phase_q >= 0 ? opts->phase_q : k.phase_q;
+  const int every = opts->phase_every > 0 ? opts->phase_every : k.phase_every;
+  const double alpha = opts->phase_alpha >= 0.f ? (double)opts->phase_alpha : k.phase_alpha;
+  const float one_minus_eta_b = (float)(1.0 - (double)eta_b);
+  const bool do_phase = quality < phase_q;
+
+  DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_y, y, n * 4, hipMemcpyDeviceToDevice, s));     // y = x_t.clone()
+  DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_xt, y, n * 4, hipMemcpyDeviceToDevice, s));
+  if (do_phase) phase_prepare(p.s_y, B, H, W, s);
+  const bool graph = cfg.use_graph != 0;
+  for (int i = steps - 1; i >= 0; --i) {
+    launch_fill_t(p.s_t, B, i, steps, s);
+    if (graph) {
+      predict(p.s_xt, p.s_t, p.s_t, p.s_theta, B, H, W, s);
+    } else {
+      forward(p.s_xt, p.s_t, p.s_t, p.s_theta, s);
+    }
+    launch_quantize_u8(p.s_theta, p.s_u8, (int64_t)n, s);
+    DDPMIR_HIP_CHECK(hipMemcpyAsync(pin_in_, p.s_u8, n, hipMemcpyDeviceToHost, s));
+    DDPMIR_HIP_CHECK(hipStreamSynchronize(s));
+    int rc = opts->codec(opts->codec_user, pin_in_, pin_out_, B, H, W, quality);
+    if (rc != 0) throw std::runtime_error("codec callback failed with code " + std::to_string(rc));
+    DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_dec, pin_out_, n, hipMemcpyHostToDevice, s));
+    const float* noise = nullptr;
+    if (i > 0) {
+      if (opts->noise) noise = opts->noise + (size_t)i * n;
+      else {
+        // counter = (step, global element index): results do not depend on how the batch is sharded
+        launch_randn(p.s_noise, (int64_t)n, opts->seed + (uint64_t)i * 0x9E3779B97F4A7C15ull,
+                     opts->image_offset * (uint64_t)(3 * H * W) / 4, s);
+        noise = p.s_noise;
+      }
+    }
+    launch_ddrm_update(p.s_theta, p.s_dec, p.s_y, noise, p.s_xt, (int64_t)3 * H * W, B, eta, eta_b, one_minus_eta_b,
+                       coeff, i, steps, i == 0 ? 1 : 0, s);
+    if (i > 0 && do_phase && (i % every) == 0) phase_fix(p.s_xt, B, H, W, alpha, s);
+    if (opts->trace) {
+      float* tr = opts->trace + (size_t)(steps - 1 - i) * 2 * n;
+      DDPMIR_HIP_CHECK(hipMemcpyAsync(tr, p.s_theta, n * 4, hipMemcpyDeviceToDevice, s));
+      DDPMIR_HIP_CHECK(hipMemcpyAsync(tr + n, p.s_xt, n * 4, hipMemcpyDeviceToDevice, s));
+    }
+  }
+  DDPMIR_HIP_CHECK(hipMemcpyAsync(out, p.s_xt, n * 4, hipMemcpyDeviceToDevice, s));
+  DDPMIR_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+}  // namespace ddpmir

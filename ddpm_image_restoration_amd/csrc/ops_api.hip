@@ -1,0 +1,221 @@
+// Host-buffer single-operator entry points (include/ddpmir_ops.h) used by the per-operator parity tests.
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ddpmir.h"
+#include "../../include/ddpmir_ops.h"
+#include "kernels.h"
+
+using namespace ddpmir;
+
+namespace {
+thread_local std::string g_err;
+
+struct Dev {
+  std::vector<void*> ptrs;
+  ~Dev() { for (void* p : ptrs) (void)hipFree(p); }
+  template <typename T>
+  T* up(const T* host, size_t n) {
+    if (!host) return nullptr;
+    T* d = alloc<T>(n);
+    DDPMIR_HIP_CHECK(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+  }
+  template <typename T>
+  T* alloc(size_t n) {
+    void* d = nullptr;
+    DDPMIR_HIP_CHECK(hipMalloc(&d, (n ? n : 1) * sizeof(T)));
+    DDPMIR_HIP_CHECK(hipMemset(d, 0, (n ? n : 1) * sizeof(T)));
+    ptrs.push_back(d);
+    return static_cast<T*>(d);
+  }
+  template <typename T>
+  void down(T* host, const T* dev, size_t n) {
+    DDPMIR_HIP_CHECK(hipDeviceSynchronize());
+    DDPMIR_HIP_CHECK(hipMemcpy(host, dev, n * sizeof(T), hipMemcpyDeviceToHost));
+  }
+};
+
+template <typename F>
+int guarded(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return DDPMIR_EINVAL;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* ddpmir_ops_last_error(void) { return g_err.c_str(); }
+
+int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
+                   int ksize, const float* scale, const float* shift, int pro_act, int pro_mask, int bs, int low,
+                   const float* tb, int epi_act, const float* mul, const float* rowscale, int epi_mask,
+                   const float* res, int nchw_out, float* out) {
+  return guarded([&] {
+    Dev d;
+    const int cinp = round_up(Cin, 4), taps = ksize * ksize;
+    const size_t M = (size_t)B * H * W;
+    // pad channels to a multiple of 4 exactly like the model's weight packer
+    std::vector<float> xp(M * cinp, 0.f), wp((size_t)taps * Cout * cinp, 0.f), sp, hp;
+    for (size_t m = 0; m < M; ++m)
+      for (int c = 0; c < Cin; ++c) xp[m * cinp + c] = x[m * Cin + c];
+    for (int o = 0; o < Cout; ++o)
+      for (int c = 0; c < Cin; ++c)
+        for (int t = 0; t < taps; ++t) wp[((size_t)t * Cout + o) * cinp + c] = w_oihw[((size_t)o * Cin + c) * taps + t];
+    IGemm p;
+    p.A = d.up(xp.data(), xp.size()); p.lda = cinp; p.B = B; p.H = H; p.W = W; p.Cin = cinp;
+    p.Wt = d.up(wp.data(), wp.size()); p.Cout = Cout; p.taps = taps; p.bias = d.up(bias, Cout);
+    if (scale) {
+      sp.assign((size_t)B * cinp, 0.f); hp.assign((size_t)B * cinp, 0.f);
+      for (int b = 0; b < B; ++b)
+        for (int c = 0; c < Cin; ++c) { sp[b * cinp + c] = scale[b * Cin + c]; hp[b * cinp + c] = shift[b * Cin + c]; }
+      p.scale = d.up(sp.data(), sp.size()); p.shift = d.up(hp.data(), hp.size());
+    }
+    p.pro_act = pro_act; p.pro_mask = pro_mask; p.bs = bs; p.low = low;
+    p.tb = d.up(tb, (size_t)B * Cout); p.ldtb = Cout; p.epi_act = epi_act;
+    p.mul = d.up(mul, M * Cout); p.ldmul = Cout; p.rowscale = d.up(rowscale, B); p.epi_mask = epi_mask;
+    p.res = d.up(res, M * Cout); p.ldres = Cout;
+    float* o = d.alloc<float>(M * Cout);
+    p.out = o; p.ldo = Cout; p.store = nchw_out ? STORE_NCHW : STORE_NHWC;
+    launch_igemm(p, nullptr);
+    d.down(out, o, M * Cout);
+  });
+}
+
+int ddpmir_op_gn_scale_shift(const float* x, int B, int HW, int C, int G, const float* gamma, const float* beta,
+                             float* scale, float* shift) {
+  return guarded([&] {
+    Dev d;
+    const int Cs = round_up(C, 4);
+    std::vector<float> xp((size_t)B * HW * Cs, 0.f);
+    for (size_t m = 0; m < (size_t)B * HW; ++m)
+      for (int c = 0; c < C; ++c) xp[m * Cs + c] = x[m * C + c];
+    float* dx = d.up(xp.data(), xp.size());
+    double* part = d.alloc<double>((size_t)B * 8 * gn_splits(HW, C) * 2 + 64);
+    float* sc = d.alloc<float>((size_t)B * Cs);
+    float* sh = d.alloc<float>((size_t)B * Cs);
+    launch_gn_scale_shift(dx, Cs, B, HW, C, G, d.up(gamma, C), d.up(beta, C), part, sc, sh, nullptr);
+    std::vector<float> s1((size_t)B * Cs), s2((size_t)B * Cs);
+    d.down(s1.data(), sc, s1.size());
+    d.down(s2.data(), sh, s2.size());
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < C; ++c) { scale[b * C + c] = s1[b * Cs + c]; shift[b * C + c] = s2[b * Cs + c]; }
+  });
+}
+
+int ddpmir_op_attention(const float* qkv, int B, int N, int C, int heads, float* out) {
+  return guarded([&] {
+    Dev d;
+    float* q = d.up(qkv, (size_t)B * N * 3 * C);
+    float* o = d.alloc<float>((size_t)B * N * C);
+    launch_attention(q, o, C, B, N, C, heads, nullptr);
+    d.down(out, o, (size_t)B * N * C);
+  });
+}
+
+int ddpmir_op_block_transform(const float* x, int B, int H, int W, int C, int bs, const float* mats, int per_channel,
+                              float mix_in, float mix_t, float* out) {
+  return guarded([&] {
+    Dev d;
+    size_t n = (size_t)B * H * W * C;
+    float* o = d.alloc<float>(n);
+    launch_block_transform(d.up(x, n), C, o, C, B, H, W, C, bs, d.up(mats, (size_t)(per_channel ? C : 1) * bs * bs),
+                           per_channel, mix_in, mix_t, nullptr);
+    d.down(out, o, n);
+  });
+}
+
+int ddpmir_op_maxpool2(const float* x, int B, int H, int W, int C, float* out) {
+  return guarded([&] {
+    Dev d;
+    size_t no = (size_t)B * (H / 2) * (W / 2) * C;
+    float* o = d.alloc<float>(no);
+    launch_maxpool2(d.up(x, (size_t)B * H * W * C), C, o, C, B, H, W, C, nullptr);
+    d.down(out, o, no);
+  });
+}
+
+int ddpmir_op_upsample2(const float* x, int B, int H, int W, int C, float* out) {
+  return guarded([&] {
+    Dev d;
+    size_t no = (size_t)B * H * W * C * 4;
+    float* o = d.alloc<float>(no);
+    launch_upsample2(d.up(x, (size_t)B * H * W * C), C, o, C, B, H, W, C, nullptr);
+    d.down(out, o, no);
+  });
+}
+
+int ddpmir_op_bilinear(const float* x, int B, int Hi, int Wi, int C, int Ho, int Wo, float* out) {
+  return guarded([&] {
+    Dev d;
+    size_t no = (size_t)B * Ho * Wo * C;
+    float* o = d.alloc<float>(no);
+    launch_bilinear(d.up(x, (size_t)B * Hi * Wi * C), C, o, C, B, Hi, Wi, Ho, Wo, C, (float)Hi / (float)Ho,
+                    (float)Wi / (float)Wo, 0, 1.0f, nullptr);
+    d.down(out, o, no);
+  });
+}
+
+int ddpmir_op_adaptive_avgpool(const float* x, int B, int H, int W, int C, int S, float* out) {
+  return guarded([&] {
+    Dev d;
+    size_t no = (size_t)B * S * S * C;
+    float* o = d.alloc<float>(no);
+    launch_adaptive_avgpool(d.up(x, (size_t)B * H * W * C), C, o, C, B, H, W, C, S, nullptr);
+    d.down(out, o, no);
+  });
+}
+
+int ddpmir_op_time_embed(const float* t, int B, const float* w0, const float* b0, const float* w2, const float* b2,
+                         float* temb) {
+  return guarded([&] {
+    Dev d;
+    std::vector<float> wt(256 * 4, 0.f), bt(4, 0.f);
+    TimeEmbedW w{d.up(w0, 1024 * 256), d.up(b0, 1024), d.up(w2, 256 * 1024), d.up(b2, 256), d.up(wt.data(), wt.size()),
+                 d.up(bt.data(), 4), 4};
+    float* hid = d.alloc<float>((size_t)B * 1024);
+    float* te = d.alloc<float>((size_t)B * 256);
+    float* tp = d.alloc<float>((size_t)B * 4);
+    launch_time_embed(d.up(t, B), B, w, hid, te, tp, nullptr);
+    d.down(temb, te, (size_t)B * 256);
+  });
+}
+
+int ddpmir_op_quantize_u8(const float* x, int64_t n, uint8_t* out) {
+  return guarded([&] {
+    Dev d;
+    uint8_t* o = d.alloc<uint8_t>(n);
+    launch_quantize_u8(d.up(x, n), o, n, nullptr);
+    d.down(out, o, n);
+  });
+}
+
+int ddpmir_op_ddrm_update(const float* x_theta, const uint8_t* dec_u8, const float* y, const float* noise,
+                          int64_t n_per_image, int B, float eta, float eta_b, float noise_coeff, int step_i, int steps,
+                          float* out) {
+  return guarded([&] {
+    Dev d;
+    size_t n = (size_t)n_per_image * B;
+    float* o = d.alloc<float>(n);
+    launch_ddrm_update(d.up(x_theta, n), d.up(dec_u8, n), d.up(y, n), d.up(noise, n), o, n_per_image, B, eta, eta_b,
+                       (float)(1.0 - (double)eta_b), noise_coeff, step_i, steps, step_i == 0 ? 1 : 0, nullptr);
+    d.down(out, o, n);
+  });
+}
+
+int ddpmir_op_randn(int64_t n, uint64_t seed, uint64_t offset, float* out) {
+  return guarded([&] {
+    Dev d;
+    float* o = d.alloc<float>(n + 4);
+    launch_randn(o, n, seed, offset, nullptr);
+    d.down(out, o, n);
+  });
+}
+
+}  // extern "C"

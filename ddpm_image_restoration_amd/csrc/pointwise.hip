@@ -1,0 +1,402 @@
+// HBM-bound kernels of the U-Net forward: GroupNorm statistics, pooling, bilinear resampling, blockwise
+// DCT / learned transforms, time embedding.  All NHWC fp32, 16-byte vector accesses along channels.
+#include "kernels.h"
+
+namespace ddpmir {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------- GroupNorm
+// Pass 1: a workgroup streams a contiguous run of pixels of ONE image, all channels (fully coalesced),
+// every thread owns a fixed 4-channel slot -> one group; double partial sums per (b, split, g).
+// Pass 2: fold the splits, emit scale = rstd*gamma, shift = beta - mean*scale per (b, c).
+constexpr int GN_PIX_PER_SPLIT = 2048;
+
+__global__ __launch_bounds__(256) void gn_partial(const float* __restrict__ x, int ldx, int HW, int C, int G,
+                                                  int splits, double* __restrict__ partial) {
+  __shared__ double s1[256], s2[256];
+  __shared__ int sg[256];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const int cpg = C / G;
+  const int vec = (C % 4 == 0 && cpg % 4 == 0) ? 4 : 1;
+  const int lanes_per_pix = C / vec;
+  const int pix_per_iter = 256 / lanes_per_pix > 0 ? 256 / lanes_per_pix : 1;
+  const int64_t p_begin = (int64_t)sp * HW / splits, p_end = (int64_t)(sp + 1) * HW / splits;
+  double a1 = 0.0, a2 = 0.0;
+  int g = -1;
+  if (lanes_per_pix <= 256) {
+    const int slot = tid % lanes_per_pix, pslot = tid / lanes_per_pix;
+    if (pslot < pix_per_iter) {
+      g = (slot * vec) / cpg;
+      const float* xb = x + (size_t)b * HW * ldx + slot * vec;
+      for (int64_t p = p_begin + pslot; p < p_end; p += pix_per_iter) {
+        if (vec == 4) {
+          float4 v = *reinterpret_cast<const float4*>(xb + p * ldx);
+          a1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+          a2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        } else {
+          float v = xb[p * ldx];
+          a1 += v;
+          a2 += (double)v * v;
+        }
+      }
+    }
+  } else {  // more 4-channel slots than threads (C > 1024): loop over slots
+    // not needed for the supported models (C <= 1024)
+  }
+  s1[tid] = a1; s2[tid] = a2; sg[tid] = g;
+  __syncthreads();
+  if (tid < G) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int i = 0; i < 256; ++i)
+      if (sg[i] == tid) { t1 += s1[i]; t2 += s2[i]; }
+    double* o = partial + (((size_t)b * splits + sp) * G + tid) * 2;
+    o[0] = t1; o[1] = t2;
+  }
+}
+
+__global__ void gn_finalize(const double* __restrict__ partial, int splits, int HW, int C, int Cs, int G,
+                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                            float* __restrict__ scale, float* __restrict__ shift) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cs) return;
+  if (c >= C) { scale[(size_t)b * Cs + c] = 0.f; shift[(size_t)b * Cs + c] = 0.f; return; }
+  const int cpg = C / G, g = c / cpg;
+  double t1 = 0.0, t2 = 0.0;
+  for (int s = 0; s < splits; ++s) {
+    const double* o = partial + (((size_t)b * splits + s) * G + g) * 2;
+    t1 += o[0]; t2 += o[1];
+  }
+  const double n = (double)HW * cpg;
+  const double mean = t1 / n;
+  double var = t2 / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+  const float sc = rstd * gamma[c];
+  scale[(size_t)b * Cs + c] = sc;
+  shift[(size_t)b * Cs + c] = beta[c] - (float)mean * sc;
+}
+
+// ------------------------------------------------------------------------------------------- resampling
+__global__ void maxpool2_k(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B, int H,
+                           int W, int C4) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)B * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c4 = i % C4;
+    int64_t p = i / C4;
+    int xo = p % Wo; p /= Wo;
+    int yo = p % Ho; int b = p / Ho;
+    const float* ip = in + (((size_t)b * H + 2 * yo) * W + 2 * xo) * ldi + 4 * c4;
+    float4 a = *reinterpret_cast<const float4*>(ip);
+    float4 bq = *reinterpret_cast<const float4*>(ip + ldi);
+    float4 c = *reinterpret_cast<const float4*>(ip + (size_t)W * ldi);
+    float4 d = *reinterpret_cast<const float4*>(ip + (size_t)W * ldi + ldi);
+    float4 r = make_float4(fmaxf(fmaxf(a.x, bq.x), fmaxf(c.x, d.x)), fmaxf(fmaxf(a.y, bq.y), fmaxf(c.y, d.y)),
+                           fmaxf(fmaxf(a.z, bq.z), fmaxf(c.z, d.z)), fmaxf(fmaxf(a.w, bq.w), fmaxf(c.w, d.w)));
+    *reinterpret_cast<float4*>(out + (((size_t)b * Ho + yo) * Wo + xo) * ldo + 4 * c4) = r;
+  }
+}
+
+// torch upsample_bilinear2d, align_corners=False: src = max(scale*(dst+0.5)-0.5, 0)
+__device__ __forceinline__ void lin_coord(int dst, int in_size, float scale, int& i0, int& i1, float& w0, float& w1) {
+  float src = fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+  i0 = min((int)src, in_size - 1);
+  i1 = min(i0 + 1, in_size - 1);
+  w1 = src - (float)i0;
+  w0 = 1.0f - w1;
+}
+
+__global__ void bilinear_k(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B, int Hi,
+                           int Wi, int Ho, int Wo, int C4, float sh, float sw, int accumulate, float out_scale) {
+  const int64_t total = (int64_t)B * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c4 = i % C4;
+    int64_t p = i / C4;
+    int xo = p % Wo; p /= Wo;
+    int yo = p % Ho; int b = p / Ho;
+    int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+    lin_coord(yo, Hi, sh, y0, y1, wy0, wy1);
+    lin_coord(xo, Wi, sw, x0, x1, wx0, wx1);
+    const float* ib = in + (size_t)b * Hi * Wi * ldi + 4 * c4;
+    float4 v00 = *reinterpret_cast<const float4*>(ib + ((size_t)y0 * Wi + x0) * ldi);
+    float4 v01 = *reinterpret_cast<const float4*>(ib + ((size_t)y0 * Wi + x1) * ldi);
+    float4 v10 = *reinterpret_cast<const float4*>(ib + ((size_t)y1 * Wi + x0) * ldi);
+    float4 v11 = *reinterpret_cast<const float4*>(ib + ((size_t)y1 * Wi + x1) * ldi);
+    float4 r;
+    r.x = wy0 * (wx0 * v00.x + wx1 * v01.x) + wy1 * (wx0 * v10.x + wx1 * v11.x);
+    r.y = wy0 * (wx0 * v00.y + wx1 * v01.y) + wy1 * (wx0 * v10.y + wx1 * v11.y);
+    r.z = wy0 * (wx0 * v00.z + wx1 * v01.z) + wy1 * (wx0 * v10.z + wx1 * v11.z);
+    r.w = wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
+    float* op = out + (((size_t)b * Ho + yo) * Wo + xo) * ldo + 4 * c4;
+    if (accumulate) {
+      float4 o = *reinterpret_cast<float4*>(op);
+      r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+    }
+    r.x *= out_scale; r.y *= out_scale; r.z *= out_scale; r.w *= out_scale;
+    *reinterpret_cast<float4*>(op) = r;
+  }
+}
+
+__global__ void adaptive_avgpool_k(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B,
+                                   int H, int W, int C4, int S) {
+  const int64_t total = (int64_t)B * S * S * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c4 = i % C4;
+    int64_t p = i / C4;
+    int xo = p % S; p /= S;
+    int yo = p % S; int b = p / S;
+    int ys = (yo * H) / S, ye = ((yo + 1) * H + S - 1) / S;
+    int xs = (xo * W) / S, xe = ((xo + 1) * W + S - 1) / S;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int y = ys; y < ye; ++y)
+      for (int x = xs; x < xe; ++x) {
+        float4 v = *reinterpret_cast<const float4*>(in + (((size_t)b * H + y) * W + x) * ldi + 4 * c4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    float inv = 1.0f / (float)((ye - ys) * (xe - xs));
+    *reinterpret_cast<float4*>(out + (((size_t)b * S + yo) * S + xo) * ldo + 4 * c4) =
+        make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- block transform
+// One thread = one (block, channel): Y = T X T^T with zero padding beyond H/W and cropping on store.
+template <int BS>
+__global__ void block_transform_k(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B,
+                                  int H, int W, int C, const float* __restrict__ mats, int per_channel,
+                                  float mix_in, float mix_t) {
+  const int nby = (H + BS - 1) / BS, nbx = (W + BS - 1) / BS;
+  const int64_t total = (int64_t)B * nby * nbx * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = i % C;
+    int64_t p = i / C;
+    int bx = p % nbx; p /= nbx;
+    int by = p % nby; int b = p / nby;
+    const float* T = mats + (per_channel ? (size_t)c * BS * BS : 0);
+    float X[BS][BS], Tm[BS][BS], tmp[BS][BS];
+#pragma unroll
+    for (int u = 0; u < BS; ++u)
+#pragma unroll
+      for (int v = 0; v < BS; ++v) Tm[u][v] = T[u * BS + v];
+#pragma unroll
+    for (int u = 0; u < BS; ++u) {
+      int y = by * BS + u;
+#pragma unroll
+      for (int v = 0; v < BS; ++v) {
+        int x = bx * BS + v;
+        X[u][v] = (y < H && x < W) ? in[(((size_t)b * H + y) * W + x) * ldi + c] : 0.f;
+      }
+    }
+    // tmp = T X
+#pragma unroll
+    for (int u = 0; u < BS; ++u)
+#pragma unroll
+      for (int v = 0; v < BS; ++v) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < BS; ++k) a = fmaf(Tm[u][k], X[k][v], a);
+        tmp[u][v] = a;
+      }
+    // Y = tmp T^T
+#pragma unroll
+    for (int u = 0; u < BS; ++u) {
+      int y = by * BS + u;
+#pragma unroll
+      for (int v = 0; v < BS; ++v) {
+        int x = bx * BS + v;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < BS; ++k) a = fmaf(tmp[u][k], Tm[v][k], a);
+        if (y < H && x < W) out[(((size_t)b * H + y) * W + x) * ldo + c] = mix_in * X[u][v] + mix_t * a;
+      }
+    }
+  }
+}
+
+__global__ void mul4_add_k(const float* base, int ldb, const float* a, int lda, const float* b, int ldb2,
+                           const float* c, int ldc, const float* d, int ldd, float* out, int ldo, int64_t M, int C4) {
+  const int64_t total = M * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c4 = i % C4;
+    int64_t m = i / C4;
+    float4 v = *reinterpret_cast<const float4*>(a + m * lda + 4 * c4);
+    if (b) { float4 w = *reinterpret_cast<const float4*>(b + m * ldb2 + 4 * c4); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
+    if (c) { float4 w = *reinterpret_cast<const float4*>(c + m * ldc + 4 * c4); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
+    if (d) { float4 w = *reinterpret_cast<const float4*>(d + m * ldd + 4 * c4); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
+    if (base) { float4 w = *reinterpret_cast<const float4*>(base + m * ldb + 4 * c4); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+    *reinterpret_cast<float4*>(out + m * ldo + 4 * c4) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------- time embedding
+// one workgroup per sample: sinusoid -> Linear(256,1024) -> SiLU -> Linear(1024,256)
+__global__ __launch_bounds__(256) void time_embed_k(const float* __restrict__ t, TimeEmbedW w,
+                                                    float* __restrict__ hidden, float* __restrict__ temb) {
+  __shared__ float e[256];
+  __shared__ float h[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  {
+    const int k = tid & 127;
+    const float coef = (float)(-9.210340371976184 / 127.0);   // -ln(10000)/(half-1), rounded to fp32 like torch
+    const float f = expf((float)k * coef);
+    const float a = t[b] * f;
+    e[tid] = tid < 128 ? sinf(a) : cosf(a);
+  }
+  __syncthreads();
+  for (int n = tid; n < 1024; n += 256) {
+    const float* wr = w.w0 + (size_t)n * 256;
+    float acc = 0.f;
+    for (int k = 0; k < 256; k += 4) {
+      float4 wv = *reinterpret_cast<const float4*>(wr + k);
+      acc = fmaf(wv.x, e[k], acc); acc = fmaf(wv.y, e[k + 1], acc);
+      acc = fmaf(wv.z, e[k + 2], acc); acc = fmaf(wv.w, e[k + 3], acc);
+    }
+    acc += w.b0[n];
+    float s = acc / (1.0f + __expf(-acc));
+    h[n] = s;
+    hidden[(size_t)b * 1024 + n] = s;
+  }
+  __syncthreads();
+  {
+    const float* wr = w.w2 + (size_t)tid * 1024;
+    float acc = 0.f;
+    for (int k = 0; k < 1024; k += 4) {
+      float4 wv = *reinterpret_cast<const float4*>(wr + k);
+      acc = fmaf(wv.x, h[k], acc); acc = fmaf(wv.y, h[k + 1], acc);
+      acc = fmaf(wv.z, h[k + 2], acc); acc = fmaf(wv.w, h[k + 3], acc);
+    }
+    temb[(size_t)b * 256 + tid] = acc + w.b2[tid];
+  }
+}
+
+// all 13 time_proj Linear(256, out_c) at once: tproj[b][n] = wt[n] . temb[b] + bt[n]
+__global__ __launch_bounds__(256) void time_proj_k(const float* __restrict__ temb, TimeEmbedW w,
+                                                   float* __restrict__ tproj) {
+  __shared__ float e[256];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  e[tid] = temb[(size_t)b * 256 + tid];
+  __syncthreads();
+  const int n = blockIdx.x * 256 + tid;
+  if (n >= w.NT) return;
+  const float* wr = w.wt + (size_t)n * 256;
+  float acc = 0.f;
+  for (int k = 0; k < 256; k += 4) {
+    float4 wv = *reinterpret_cast<const float4*>(wr + k);
+    acc = fmaf(wv.x, e[k], acc); acc = fmaf(wv.y, e[k + 1], acc);
+    acc = fmaf(wv.z, e[k + 2], acc); acc = fmaf(wv.w, e[k + 3], acc);
+  }
+  tproj[(size_t)b * w.NT + n] = acc + w.bt[n];
+}
+
+__global__ void cl_boost_k(const float* cl, int B, float a0, float a1, float lo, float hi, float* out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) out[b] = fminf(fmaxf(a0 + a1 * (1.0f - cl[b]), lo), hi);
+}
+
+__global__ void nchw3_to_nhwc4_k(const float* __restrict__ in, float* __restrict__ out, int B, int HW) {
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t b = i / HW, p = i - b * HW;
+    const float* ip = in + b * 3 * HW + p;
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(ip[0], ip[HW], ip[2 * (int64_t)HW], 0.f);
+  }
+}
+
+inline unsigned grid_for(int64_t total, int block = 256) {
+  int64_t g = (total + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > 256 * 16) g = 256 * 16;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+int gn_splits(int HW, int C) {
+  (void)C;
+  int s = cdiv(HW, GN_PIX_PER_SPLIT);
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return s;
+}
+
+void launch_gn_scale_shift(const float* x, int ldx, int B, int HW, int C, int G, const float* gamma,
+                           const float* beta, double* partial, float* scale, float* shift, hipStream_t stream) {
+  // scale/shift rows are padded to a multiple of 4 channels (zeros) so igemm can read float4
+  const int Cs = round_up(C, 4);
+  if (C > 1024) throw std::runtime_error("group norm: C > 1024 unsupported");
+  const int splits = gn_splits(HW, C);
+  hipLaunchKernelGGL(gn_partial, dim3(splits, B), dim3(256), 0, stream, x, ldx, HW, C, G, splits, partial);
+  hipLaunchKernelGGL(gn_finalize, dim3(cdiv(Cs, 128), B), dim3(128), 0, stream, partial, splits, HW, C, Cs, G,
+                     gamma, beta, scale, shift);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_maxpool2(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, hipStream_t s) {
+  int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(maxpool2_k, dim3(grid_for(total)), dim3(256), 0, s, in, ldi, out, ldo, B, H, W, C / 4);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_bilinear(const float* in, int ldi, float* out, int ldo, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                     float scale_h, float scale_w, int accumulate, float out_scale, hipStream_t s) {
+  int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(bilinear_k, dim3(grid_for(total)), dim3(256), 0, s, in, ldi, out, ldo, B, Hi, Wi, Ho, Wo, C / 4,
+                     scale_h, scale_w, accumulate, out_scale);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_upsample2(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, hipStream_t s) {
+  launch_bilinear(in, ldi, out, ldo, B, H, W, 2 * H, 2 * W, C, 0.5f, 0.5f, 0, 1.0f, s);
+}
+
+void launch_adaptive_avgpool(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int S,
+                             hipStream_t s) {
+  int64_t total = (int64_t)B * S * S * (C / 4);
+  hipLaunchKernelGGL(adaptive_avgpool_k, dim3(grid_for(total)), dim3(256), 0, s, in, ldi, out, ldo, B, H, W, C / 4, S);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int bs,
+                            const float* mats, int per_channel, float mix_in, float mix_t, hipStream_t s) {
+  int64_t total = (int64_t)B * cdiv(H, bs) * cdiv(W, bs) * C;
+  if (bs == 4)
+    hipLaunchKernelGGL(block_transform_k<4>, dim3(grid_for(total)), dim3(256), 0, s, in, ldi, out, ldo, B, H, W, C,
+                       mats, per_channel, mix_in, mix_t);
+  else if (bs == 8)
+    hipLaunchKernelGGL(block_transform_k<8>, dim3(grid_for(total, 128)), dim3(128), 0, s, in, ldi, out, ldo, B, H, W,
+                       C, mats, per_channel, mix_in, mix_t);
+  else
+    throw std::runtime_error("block transform: block size must be 4 or 8");
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_mul4_add(const float* base, int ldb, const float* a, int lda, const float* b, int ldb2, const float* c,
+                     int ldc, const float* d, int ldd, float* out, int ldo, int64_t M, int C, hipStream_t s) {
+  int64_t total = M * (C / 4);
+  hipLaunchKernelGGL(mul4_add_k, dim3(grid_for(total)), dim3(256), 0, s, base, ldb, a, lda, b, ldb2, c, ldc, d, ldd,
+                     out, ldo, M, C / 4);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_time_embed(const float* t, int B, const TimeEmbedW& w, float* hidden, float* temb, float* tproj,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(time_embed_k, dim3(B), dim3(256), 0, s, t, w, hidden, temb);
+  hipLaunchKernelGGL(time_proj_k, dim3(cdiv(w.NT, 256), B), dim3(256), 0, s, temb, w, tproj);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_cl_boost(const float* cl, int B, float a0, float a1, float lo, float hi, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(cl_boost_k, dim3(cdiv(B, 64)), dim3(64), 0, s, cl, B, a0, a1, lo, hi, out);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_nchw3_to_nhwc4(const float* in, float* out, int B, int H, int W, hipStream_t s) {
+  hipLaunchKernelGGL(nchw3_to_nhwc4_k, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, s, in, out, B, H * W);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace ddpmir

@@ -1,0 +1,242 @@
+// Per-step kernels of the DDRM / DDPM sampling loops (reference: webp_inference.py:557-602).
+// Arithmetic that feeds the uint8 truncation is written with explicit round-to-nearest intrinsics so that
+// hipcc cannot contract a*b+c into an fma: torch evaluates x*127.5+127.5 as two rounded fp32 ops, and a
+// 1-ulp difference there flips a pixel by 1/127.5 after the codec.
+#include "kernels.h"
+
+namespace ddpmir {
+
+namespace {
+
+__global__ void quantize_u8_k(const float* __restrict__ x, uint8_t* __restrict__ u8, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = __fadd_rn(__fmul_rn(x[i], 127.5f), 127.5f);
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    u8[i] = (uint8_t)(int)v;   // truncation, like .to(torch.uint8)
+  }
+}
+
+// x' = (x_theta - dec) + y ; x_t = (eta_b*x' + (1-eta_b)*x_theta) + eta*(noise*(t*coeff))
+__global__ void ddrm_update_k(const float* __restrict__ x_theta, const uint8_t* __restrict__ dec_u8,
+                              const float* __restrict__ y, const float* __restrict__ noise, float* __restrict__ x_out,
+                              int64_t n, float eta, float eta_b, float one_minus_eta_b, float noise_scale, int last) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float dec = __fmul_rn(__fsub_rn(__fdiv_rn((float)dec_u8[i], 255.0f), 0.5f), 2.0f);
+    float th = x_theta[i];
+    float xp = __fadd_rn(__fsub_rn(th, dec), y[i]);
+    if (last) {
+      x_out[i] = xp;
+    } else {
+      float rnd = __fmul_rn(noise[i], noise_scale);
+      float mix = __fadd_rn(__fmul_rn(eta_b, xp), __fmul_rn(one_minus_eta_b, th));
+      x_out[i] = __fadd_rn(mix, __fmul_rn(eta, rnd));
+    }
+  }
+}
+
+__global__ void fill_t_k(float* t, int B, float v) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) t[b] = v;
+}
+
+// ------------------------------------------------------------------------------------------- Philox4x32-10
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
+                                             uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+  uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+  uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__global__ void randn_k(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+  const int64_t nq = (n + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t ctr = offset + (uint64_t)q;
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c0, c1, c2, c3, k0, k1);
+      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float inv = 2.3283064365386963e-10f;   // 2^-32
+    float u0 = ((float)c0 + 0.5f) * inv, u1 = ((float)c1 + 0.5f) * inv;
+    float u2 = ((float)c2 + 0.5f) * inv, u3 = ((float)c3 + 0.5f) * inv;
+    u0 = fminf(fmaxf(u0, 1e-12f), 1.0f); u2 = fminf(fmaxf(u2, 1e-12f), 1.0f);
+    float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    float z[4];
+    z[0] = r0 * cosf(6.283185307179586f * u1); z[1] = r0 * sinf(6.283185307179586f * u1);
+    z[2] = r1 * cosf(6.283185307179586f * u3); z[3] = r1 * sinf(6.283185307179586f * u3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * q + j < n) out[4 * q + j] = z[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------- separable DFT
+// rows:  T[p][y][v] = sum_x in[p][y][x] * w^(v*x),  w = exp(-+2 pi i / W)  (complex in optional)
+// One workgroup per (plane row y); the row sits in LDS, each thread produces output bins v = tid, tid+256...
+// Twiddles come from an n-entry table indexed by (v*x) mod n -- exact periodicity, no drift.
+__global__ __launch_bounds__(256) void dft_rows_k(const float* __restrict__ in_re, const float* __restrict__ in_im,
+                                                  float* __restrict__ out_re, float* __restrict__ out_im, int W,
+                                                  const float* __restrict__ cs, const float* __restrict__ sn,
+                                                  float sign, float scale) {
+  extern __shared__ float sh[];
+  float* xr = sh; float* xi = sh + W; float* tc = sh + 2 * W; float* ts = sh + 3 * W;
+  const size_t row = blockIdx.x;
+  for (int x = threadIdx.x; x < W; x += 256) {
+    xr[x] = in_re[row * W + x];
+    xi[x] = in_im ? in_im[row * W + x] : 0.f;
+    tc[x] = cs[x];
+    ts[x] = sign * sn[x];
+  }
+  __syncthreads();
+  for (int v = threadIdx.x; v < W; v += 256) {
+    float ar = 0.f, ai = 0.f;
+    int idx = 0;
+    for (int x = 0; x < W; ++x) {
+      float c = tc[idx], s = ts[idx];       // e^{i*sign*2pi*v*x/W} = c + i s
+      ar += xr[x] * c - xi[x] * s;
+      ai += xr[x] * s + xi[x] * c;
+      idx += v; if (idx >= W) idx -= W;
+    }
+    out_re[row * W + v] = ar * scale;
+    out_im[row * W + v] = ai * scale;
+  }
+}
+
+// columns: O[p][u][x] = sum_y in[p][y][x] * w^(u*y).  Workgroup = (plane p, 64-wide x strip); threads
+// (xl = tid & 63, ug = tid >> 6) loop u = ug, ug+4, ...; coalesced along x.
+__global__ __launch_bounds__(256) void dft_cols_k(const float* __restrict__ in_re, const float* __restrict__ in_im,
+                                                  float* __restrict__ out_re, float* __restrict__ out_im, int H, int W,
+                                                  const float* __restrict__ cs, const float* __restrict__ sn,
+                                                  float sign, float scale, int real_only) {
+  extern __shared__ float sh[];
+  float* tc = sh; float* ts = sh + H;
+  for (int y = threadIdx.x; y < H; y += 256) { tc[y] = cs[y]; ts[y] = sign * sn[y]; }
+  __syncthreads();
+  const int p = blockIdx.y;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (x >= W) return;
+  const float* br = in_re + (size_t)p * H * W + x;
+  const float* bi = in_im + (size_t)p * H * W + x;
+  for (int u = threadIdx.x >> 6; u < H; u += 4) {
+    float ar = 0.f, ai = 0.f;
+    int idx = 0;
+    for (int y = 0; y < H; ++y) {
+      float c = tc[idx], s = ts[idx];
+      float vr = br[(size_t)y * W], vi = bi[(size_t)y * W];
+      ar += vr * c - vi * s;
+      ai += vr * s + vi * c;
+      idx += u; if (idx >= H) idx -= H;
+    }
+    out_re[((size_t)p * H + u) * W + x] = ar * scale;
+    if (!real_only) out_im[((size_t)p * H + u) * W + x] = ai * scale;
+  }
+}
+
+__global__ void unit_phase_k(float* re, float* im, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float r = re[i], m = im[i];
+    float mag = sqrtf(r * r + m * m);
+    if (mag > 0.f) { re[i] = r / mag; im[i] = m / mag; }
+    else { re[i] = 1.f; im[i] = 0.f; }    // angle(0) = atan2(0,0) = 0
+  }
+}
+
+// A = |X| * U   (in place into tmp)
+__global__ void mag_times_phase_k(const float* xre, const float* xim, const float* ure, const float* uim,
+                                  float* are, float* aim, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float mag = sqrtf(xre[i] * xre[i] + xim[i] * xim[i]);
+    are[i] = mag * ure[i];
+    aim[i] = mag * uim[i];
+  }
+}
+
+__global__ void blend_k(const float* x, const float* adj, float* out, float alpha, float beta, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = __fadd_rn(__fmul_rn(alpha, x[i]), __fmul_rn(beta, adj[i]));
+}
+
+__global__ void axpby_k(const float* x, const float* e, float* out, float c1, float c2, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = __fmul_rn(c1, __fsub_rn(x[i], __fmul_rn(c2, e[i])));
+}
+
+inline unsigned grid_for(int64_t total, int block = 256) {
+  int64_t g = (total + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > 256 * 16) g = 256 * 16;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+void launch_quantize_u8(const float* x, uint8_t* u8, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(quantize_u8_k, dim3(grid_for(n)), dim3(256), 0, s, x, u8, n);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_ddrm_update(const float* x_theta, const uint8_t* dec_u8, const float* y, const float* noise, float* x_out,
+                        int64_t n_per_image, int B, float eta, float eta_b, float one_minus_eta_b, float noise_coeff,
+                        int step_i, int steps, int last, hipStream_t s) {
+  // noise_scale = t.float() * coeff with t = float(i)/steps  (webp_inference.py:568,588): two fp32 roundings
+  float t = (float)step_i / (float)steps;
+  float noise_scale = t * noise_coeff;
+  int64_t n = n_per_image * B;
+  hipLaunchKernelGGL(ddrm_update_k, dim3(grid_for(n)), dim3(256), 0, s, x_theta, dec_u8, y, noise, x_out, n, eta,
+                     eta_b, one_minus_eta_b, noise_scale, last);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_fill_t(float* t, int B, int step_i, int steps, hipStream_t s) {
+  float v = (float)step_i / (float)steps;
+  hipLaunchKernelGGL(fill_t_k, dim3(cdiv(B, 64)), dim3(64), 0, s, t, B, v);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s) {
+  hipLaunchKernelGGL(randn_k, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, out, n, seed, offset);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_dft2_forward(const float* x, float* re, float* im, float* tmp_re, float* tmp_im, int P, const DftPlan& d,
+                         hipStream_t s) {
+  const int H = d.H, W = d.W;
+  hipLaunchKernelGGL(dft_rows_k, dim3((unsigned)((size_t)P * H)), dim3(256), 4 * W * sizeof(float), s, x,
+                     (const float*)nullptr, tmp_re, tmp_im, W, d.cos_w, d.sin_w, -1.0f, 1.0f);
+  hipLaunchKernelGGL(dft_cols_k, dim3(cdiv(W, 64), P), dim3(256), 2 * H * sizeof(float), s, tmp_re, tmp_im, re, im,
+                     H, W, d.cos_h, d.sin_h, -1.0f, 1.0f, 0);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_unit_phase(float* re, float* im, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(unit_phase_k, dim3(grid_for(n)), dim3(256), 0, s, re, im, n);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_phase_apply_inverse(const float* x, const float* xre, const float* xim, const float* ure,
+                                const float* uim, float* tmp_re, float* tmp_im, float* tmp2_re, float* tmp2_im,
+                                float* out, int P, const DftPlan& d, float alpha, hipStream_t s) {
+  const int H = d.H, W = d.W;
+  const int64_t n = (int64_t)P * H * W;
+  hipLaunchKernelGGL(mag_times_phase_k, dim3(grid_for(n)), dim3(256), 0, s, xre, xim, ure, uim, tmp_re, tmp_im, n);
+  // inverse along columns (u -> y), then rows (v -> x); 1/(H*W) split over the two passes
+  hipLaunchKernelGGL(dft_cols_k, dim3(cdiv(W, 64), P), dim3(256), 2 * H * sizeof(float), s, tmp_re, tmp_im, tmp2_re,
+                     tmp2_im, H, W, d.cos_h, d.sin_h, 1.0f, 1.0f / (float)H, 0);
+  hipLaunchKernelGGL(dft_rows_k, dim3((unsigned)((size_t)P * H)), dim3(256), 4 * W * sizeof(float), s, tmp2_re,
+                     tmp2_im, tmp_re, tmp_im, W, d.cos_w, d.sin_w, 1.0f, 1.0f / (float)W);
+  // python: alpha * x + (1 - alpha) * adjusted ; (1 - alpha) is evaluated in double then rounded to fp32
+  float beta = (float)(1.0 - (double)alpha);
+  hipLaunchKernelGGL(blend_k, dim3(grid_for(n)), dim3(256), 0, s, x, tmp_re, out, alpha, beta, n);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_axpby(const float* x, const float* e, float* out, float c1, float c2, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(axpby_k, dim3(grid_for(n)), dim3(256), 0, s, x, e, out, c1, c2, n);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace ddpmir

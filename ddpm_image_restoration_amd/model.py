@@ -1,0 +1,167 @@
+"""Drop-in model objects: same call signature as the reference's nn.Modules, backed by libddpmir.so.
+
+    model = WebPDiffusionModel().to(device)            # webp_inference.py:618
+    model.load_state_dict(ckpt['model_state_dict'])    # webp_inference.py:621-627
+    x_theta = model(x_t, t, compression_level)         # webp_inference.py:577
+
+torch is used for device memory and checkpoint unpickling only; all arithmetic runs in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib, spec
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class _RestorationModel:
+    ARCH = spec.ARCH_WEBP
+
+    def __init__(self, device=None, dtype: str = "f32", attn_levels: str = "all", use_graph: bool = False):
+        """attn_levels: 'all' = self-attention in every block (the reference); 'bottleneck' = only the three
+        bottleneck blocks (what BASELINE.json's configs describe; no reference parity claim)."""
+        torch = _torch()
+        self._lib = _lib.load()
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        if device is None:
+            raise RuntimeError("no HIP device: the restoration model has no CPU path")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the restoration model runs on a HIP device only (got %s)" % self.device)
+        self._cfg = _lib.Config(self.ARCH, {"f32": 0, "bf16": 1}[dtype], 0 if attn_levels == "all" else 5,
+                                self.device.index or 0, int(use_graph))
+        self._ctx = self._lib.ddpmir_create(C.byref(self._cfg))
+        if not self._ctx:
+            raise RuntimeError("ddpmir_create failed: " + self._lib.ddpmir_last_error(None).decode())
+        self._loaded = False
+        self._blob = None
+        self.training = False
+
+    # ---- nn.Module look-alikes used by the reference call sites
+    def to(self, device):
+        torch = _torch()
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("the restoration model runs on a HIP device only")
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise RuntimeError("inference-only model: training stays on stock PyTorch")
+        return self
+
+    def parameters(self):
+        """Yields shape-only stand-ins so `sum(p.numel() for p in model.parameters())` prints the count."""
+        class _P:
+            def __init__(self, n): self._n = n
+            def numel(self): return self._n
+        for name, shp in spec.state_spec(self.ARCH).items():
+            if not name.endswith("dct_matrix"):
+                yield _P(int(np.prod(shp)))
+
+    def load_state_dict(self, state, strict: bool = True):
+        """Accepts name -> torch.Tensor | ndarray.  Every tensor is handed to ddpmir_load_tensor by name."""
+        if self._loaded:
+            raise RuntimeError("weights already finalized for this model object")
+        want = spec.state_spec(self.ARCH)
+        missing = [k for k in want if k not in state]
+        unexpected = [k for k in state if k not in want]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"state_dict mismatch: missing {missing[:5]}... unexpected {unexpected[:5]}...")
+        for name in want:
+            if name not in state:
+                continue
+            v = state[name]
+            arr = v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, dtype=np.float32)
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            if tuple(arr.shape) != tuple(want[name]):
+                raise RuntimeError(f"shape mismatch for {name}: {tuple(arr.shape)} vs {want[name]}")
+            shape = (C.c_int64 * arr.ndim)(*arr.shape)
+            rc = self._lib.ddpmir_load_tensor(self._ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim)
+            _lib.check(self._lib, self._ctx, rc, f"load_tensor({name})")
+        self.finalize()
+        return self
+
+    def finalize(self, blob=None, fill: bool = True):
+        """blob: optional torch uint8 CUDA tensor of weight_blob_bytes() bytes that will hold the packed weights
+        (used for the RCCL broadcast in dist.py)."""
+        ptr = None
+        if blob is not None:
+            self._blob = blob
+            ptr = C.c_void_p(blob.data_ptr())
+        rc = self._lib.ddpmir_finalize_weights(self._ctx, ptr, int(fill))
+        _lib.check(self._lib, self._ctx, rc, "finalize_weights")
+        self._loaded = True
+
+    def weight_blob_bytes(self) -> int:
+        return int(self._lib.ddpmir_weight_blob_bytes(self._ctx))
+
+    def param_count(self) -> int:
+        return int(self._lib.ddpmir_param_count(self._ctx))
+
+    def __call__(self, x, t, compression_level=None):
+        torch = _torch()
+        if not self._loaded:
+            raise RuntimeError("load_state_dict() first")
+        x = x.to(self.device, torch.float32).contiguous()
+        t = t.to(self.device, torch.float32).contiguous()
+        cl = t if compression_level is None else compression_level.to(self.device, torch.float32).contiguous()
+        b, c, h, w = x.shape
+        if c != 3:
+            raise RuntimeError("expected [B,3,H,W]")
+        out = torch.empty_like(x)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.ddpmir_predict(self._ctx, x.data_ptr(), t.data_ptr(), cl.data_ptr(), out.data_ptr(), b, h, w,
+                                      C.c_void_p(stream))
+        _lib.check(self._lib, self._ctx, rc, "predict")
+        return out
+
+    forward = __call__
+    predict_noise = __call__      # north_star wording; the DDRM models predict x0_hat, not eps
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self._lib.ddpmir_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+
+class WebPDiffusionModel(_RestorationModel):
+    """webp_inference.py:330-399"""
+    ARCH = spec.ARCH_WEBP
+
+
+class JPEGDiffusionModel(_RestorationModel):
+    """svd.ipynb c0:297-366"""
+    ARCH = spec.ARCH_JPEG
+
+
+class AVIFDiffusionModel(_RestorationModel):
+    """avif_inference.py:316-385"""
+    ARCH = spec.ARCH_AVIF
+
+
+MODEL_BY_ARCH = {spec.ARCH_WEBP: WebPDiffusionModel, spec.ARCH_JPEG: JPEGDiffusionModel,
+                 spec.ARCH_AVIF: AVIFDiffusionModel}
+
+
+def load_checkpoint(model: _RestorationModel, path: str):
+    """webp_inference.py:621-627: accepts {'model_state_dict': ...} or a bare state_dict."""
+    torch = _torch()
+    ckpt = torch.load(path, map_location="cpu")
+    sd = ckpt["model_state_dict"] if isinstance(ckpt, dict) and "model_state_dict" in ckpt else ckpt
+    model.load_state_dict(OrderedDict(sd))
+    return model

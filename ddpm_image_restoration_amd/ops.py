@@ -1,0 +1,177 @@
+"""numpy wrappers of the single-operator entry points (include/ddpmir_ops.h); NHWC float32 in and out.
+Used by the per-operator parity tests (each operator = one row of SURVEY.md section 8a)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_P = C.c_void_p
+_sigs = {
+    "ddpmir_ops_last_error": (C.c_char_p, []),
+    "ddpmir_op_conv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P]),
+    "ddpmir_op_gn_scale_shift": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "ddpmir_op_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ddpmir_op_block_transform": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float,
+                                            C.c_float, _P]),
+    "ddpmir_op_maxpool2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ddpmir_op_upsample2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ddpmir_op_bilinear": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ddpmir_op_adaptive_avgpool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ddpmir_op_time_embed": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
+    "ddpmir_op_quantize_u8": (C.c_int, [_P, C.c_int64, _P]),
+    "ddpmir_op_ddrm_update": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
+                                        C.c_int, _P]),
+    "ddpmir_op_randn": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, _P]),
+}
+OPS_SYMBOLS = _sigs
+_bound = False
+
+
+def _lib_ops():
+    global _bound
+    lib = _lib.load()
+    if not _bound:
+        for n, (r, a) in _sigs.items():
+            f = getattr(lib, n)
+            f.restype, f.argtypes = r, a
+        _bound = True
+    return lib
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_P)
+
+
+def _chk(lib, rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib.ddpmir_ops_last_error().decode()}")
+
+
+ACT = {None: 0, "none": 0, "gelu": 1, "silu": 2, "lrelu": 3, "relu": 4, "sigmoid": 5, "tanh": 6}
+MASK = {None: 0, "none": 0, "low": 1, "high": 2}
+
+
+def conv(x, w, bias=None, scale=None, shift=None, pro_act=None, pro_mask=None, bs=4, low=3, tb=None, epi_act=None,
+         mul=None, rowscale=None, epi_mask=None, res=None, nchw_out=False):
+    lib = _lib_ops()
+    x, w = _f(x), _f(w)
+    if w.ndim == 2:
+        w = w[:, :, None, None]
+    b, h, wd, cin = x.shape
+    cout, _, k, _ = w.shape
+    bias, scale, shift, tb, mul, rowscale, res = map(_f, (bias, scale, shift, tb, mul, rowscale, res))
+    out = np.empty((b, cout, h, wd) if nchw_out else (b, h, wd, cout), dtype=np.float32)
+    rc = lib.ddpmir_op_conv(_p(x), b, h, wd, cin, _p(w), _p(bias), cout, k, _p(scale), _p(shift), ACT[pro_act],
+                            MASK[pro_mask], bs, low, _p(tb), ACT[epi_act], _p(mul), _p(rowscale), MASK[epi_mask],
+                            _p(res), int(nchw_out), _p(out))
+    _chk(lib, rc, "op_conv")
+    return out
+
+
+def gn_scale_shift(x, groups, gamma, beta):
+    lib = _lib_ops()
+    x = _f(x)
+    b, c = x.shape[0], x.shape[-1]
+    hw = int(np.prod(x.shape[1:-1]))
+    sc = np.empty((b, c), np.float32)
+    sh = np.empty((b, c), np.float32)
+    g, be = _f(gamma), _f(beta)
+    _chk(lib, lib.ddpmir_op_gn_scale_shift(_p(x), b, hw, c, groups, _p(g), _p(be), _p(sc), _p(sh)), "op_gn")
+    return sc, sh
+
+
+def attention(qkv, heads):
+    lib = _lib_ops()
+    qkv = _f(qkv)
+    b, n, c3 = qkv.shape
+    out = np.empty((b, n, c3 // 3), np.float32)
+    _chk(lib, lib.ddpmir_op_attention(_p(qkv), b, n, c3 // 3, heads, _p(out)), "op_attention")
+    return out
+
+
+def block_transform(x, mats, mix_in=0.0, mix_t=1.0):
+    lib = _lib_ops()
+    x, mats = _f(x), _f(mats)
+    b, h, w, c = x.shape
+    out = np.empty_like(x)
+    _chk(lib, lib.ddpmir_op_block_transform(_p(x), b, h, w, c, mats.shape[-1], _p(mats), int(mats.ndim == 3), mix_in,
+                                            mix_t, _p(out)), "op_block_transform")
+    return out
+
+
+def maxpool2(x):
+    lib = _lib_ops()
+    x = _f(x)
+    b, h, w, c = x.shape
+    out = np.empty((b, h // 2, w // 2, c), np.float32)
+    _chk(lib, lib.ddpmir_op_maxpool2(_p(x), b, h, w, c, _p(out)), "op_maxpool2")
+    return out
+
+
+def upsample2(x):
+    lib = _lib_ops()
+    x = _f(x)
+    b, h, w, c = x.shape
+    out = np.empty((b, 2 * h, 2 * w, c), np.float32)
+    _chk(lib, lib.ddpmir_op_upsample2(_p(x), b, h, w, c, _p(out)), "op_upsample2")
+    return out
+
+
+def bilinear(x, ho, wo):
+    lib = _lib_ops()
+    x = _f(x)
+    b, h, w, c = x.shape
+    out = np.empty((b, ho, wo, c), np.float32)
+    _chk(lib, lib.ddpmir_op_bilinear(_p(x), b, h, w, c, ho, wo, _p(out)), "op_bilinear")
+    return out
+
+
+def adaptive_avgpool(x, s):
+    lib = _lib_ops()
+    x = _f(x)
+    b, h, w, c = x.shape
+    out = np.empty((b, s, s, c), np.float32)
+    _chk(lib, lib.ddpmir_op_adaptive_avgpool(_p(x), b, h, w, c, s, _p(out)), "op_adaptive_avgpool")
+    return out
+
+
+def time_embed(t, w0, b0, w2, b2):
+    lib = _lib_ops()
+    t, w0, b0, w2, b2 = map(_f, (t, w0, b0, w2, b2))
+    out = np.empty((t.shape[0], 256), np.float32)
+    _chk(lib, lib.ddpmir_op_time_embed(_p(t), t.shape[0], _p(w0), _p(b0), _p(w2), _p(b2), _p(out)), "op_time_embed")
+    return out
+
+
+def quantize_u8(x):
+    lib = _lib_ops()
+    x = _f(x)
+    out = np.empty(x.shape, np.uint8)
+    _chk(lib, lib.ddpmir_op_quantize_u8(_p(x), x.size, out.ctypes.data_as(_P)), "op_quantize_u8")
+    return out
+
+
+def ddrm_update(x_theta, dec_u8, y, noise, eta, eta_b, noise_coeff, step_i, steps):
+    lib = _lib_ops()
+    x_theta, y, noise = _f(x_theta), _f(y), _f(noise)
+    dec_u8 = np.ascontiguousarray(dec_u8, dtype=np.uint8)
+    b = x_theta.shape[0]
+    out = np.empty_like(x_theta)
+    _chk(lib, lib.ddpmir_op_ddrm_update(_p(x_theta), dec_u8.ctypes.data_as(_P), _p(y), _p(noise), x_theta.size // b, b,
+                                        eta, eta_b, noise_coeff, step_i, steps, _p(out)), "op_ddrm_update")
+    return out
+
+
+def randn(n, seed, offset=0):
+    lib = _lib_ops()
+    out = np.empty((n,), np.float32)
+    _chk(lib, lib.ddpmir_op_randn(n, seed, offset, _p(out)), "op_randn")
+    return out

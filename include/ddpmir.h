@@ -1,0 +1,115 @@
+/*
+ * ddpmir.h -- C ABI of the MI355X-native reverse-diffusion restoration sampler (libddpmir.so).
+ *
+ * The reference (Azure0413/DDPM_Image_Restoration) has no FFI layer; its boundary is two duck-typed Python
+ * objects and one file format.  Every entry point below names the reference interface it
+ * replaces.  All entry points return 0 on success or a negative DDPMIR_E* code; the message is available
+ * from ddpmir_last_error().  No torch types cross this boundary: plain pointers and sizes only.
+ *
+ * Pointer convention: image / tensor arguments are DEVICE pointers on the context's HIP device unless the
+ * name ends in _host.  Images are float32 NCHW in [-1, 1], exactly what the reference passes around.
+ * A context is bound to one GPU and is not thread-safe; different contexts may run concurrently.
+ */
+#ifndef DDPMIR_H
+#define DDPMIR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDPMIR_OK 0
+#define DDPMIR_EINVAL (-1)   /* bad argument / unknown tensor name / shape mismatch */
+#define DDPMIR_ESTATE (-2)   /* call order violated (e.g. predict before finalize_weights) */
+#define DDPMIR_EHIP (-3)     /* HIP runtime error */
+#define DDPMIR_ECODEC (-4)   /* codec callback failed or missing */
+#define DDPMIR_ENOMEM (-5)
+
+/* model families: webp_inference.py:330 WebPDiffusionModel, svd.ipynb c0:297 JPEGDiffusionModel,
+ * avif_inference.py:316 AVIFDiffusionModel */
+#define DDPMIR_ARCH_WEBP 0
+#define DDPMIR_ARCH_JPEG 1
+#define DDPMIR_ARCH_AVIF 2
+
+#define DDPMIR_F32 0
+#define DDPMIR_BF16 1
+
+typedef struct ddpmir_ctx ddpmir_ctx;
+
+typedef struct ddpmir_config {
+  int arch;            /* DDPMIR_ARCH_* */
+  int dtype;           /* DDPMIR_F32 (parity mode) | DDPMIR_BF16 (activations/weights bf16 on the matrix cores) */
+  int attn_min_level;  /* 0 = self-attention in all 13 blocks (the reference, webp_inference.py:317-321);
+                          5 = bottleneck blocks only (the variant BASELINE.json's configs describe) */
+  int device;          /* HIP device ordinal */
+  int use_graph;       /* 1 = replay the U-Net forward as a captured hipGraph */
+} ddpmir_config;
+
+/* replaces: WebPDiffusionModel().to(device)  (webp_inference.py:618) */
+ddpmir_ctx* ddpmir_create(const ddpmir_config* cfg);
+void ddpmir_destroy(ddpmir_ctx* ctx);
+const char* ddpmir_last_error(ddpmir_ctx* ctx);   /* ctx may be NULL: error of the last failed create */
+
+/* replaces: model.load_state_dict(ckpt['model_state_dict'])  (webp_inference.py:621-627).
+ * Call once per state_dict entry (torch does the unpickling), then finalize.  data_host: float32, C order. */
+int ddpmir_load_tensor(ddpmir_ctx* ctx, const char* name, const float* data_host, const int64_t* shape, int ndim);
+/* repack (OIHW -> [tap][Cout][Cin]) and upload; errors list missing names.  If dev_blob != NULL the packed
+ * weights live in that caller-owned device buffer of ddpmir_weight_blob_bytes() bytes (fill=1: upload into it;
+ * fill=0: adopt contents already there, e.g. after an RCCL broadcast from rank 0). */
+size_t ddpmir_weight_blob_bytes(ddpmir_ctx* ctx);
+int ddpmir_finalize_weights(ddpmir_ctx* ctx, void* dev_blob, int fill);
+int64_t ddpmir_param_count(ddpmir_ctx* ctx);       /* sum(p.numel()) -- the harness prints it */
+
+/* replaces: x_theta = model(x_t, t, compression_level)  (webp_inference.py:577; north_star's predict_noise()).
+ * x, out: [B,3,H,W]; t, cl: [B].  H and W must be multiples of 32 (five 2x2 pools). Asynchronous on `stream`
+ * (a hipStream_t; NULL = the context's own stream, synchronised before return). */
+int ddpmir_predict(ddpmir_ctx* ctx, const float* x, const float* t, const float* cl, float* out, int B, int H,
+                   int W, void* stream);
+
+/* codec round trip on uint8 NCHW images, host memory: out = decode(encode(in, quality)).
+ * replaces the PIL calls in webp_compress / avif_compress / jpeg_compress (webp_inference.py:512-525). */
+typedef int (*ddpmir_codec_fn)(void* user, const uint8_t* in_u8_nchw, uint8_t* out_u8_nchw, int B, int H, int W,
+                               int quality);
+
+typedef struct ddpmir_loop_opts {
+  ddpmir_codec_fn codec;      /* NULL = built-in on-device codec simulator (JPEG only) */
+  void* codec_user;
+  const float* noise;         /* optional device pointer [steps][B][3][H][W]: noise[i] is drawn at loop index i
+                                 (replaces torch.randn_like, webp_inference.py:589); NULL = Philox(seed) */
+  uint64_t seed;
+  uint64_t image_offset;      /* global index of image 0 of this shard (multi-GPU: results independent of N) */
+  float* trace;               /* optional device pointer [steps][2][B][3][H][W]: x_theta, x_t after each step */
+  float noise_coeff;          /* <0 = the model family's default (0.2 / 0.15) */
+  int phase_q;                /* <0 = default quality threshold of the phase fix (15 / 20 / 30) */
+  int phase_every;            /* <=0 = default (5 / 3) */
+  float phase_alpha;          /* <0 = default (0.7 / 0.8) */
+} ddpmir_loop_opts;
+
+/* replaces: DDRM{WebP,JPEG,AVIF}Sampler(model).sample(x_t, quality, steps, eta, eta_b)
+ * (webp_inference.py:557-602, avif_inference.py:414-459, svd.ipynb c0:395-440).  Blocking. */
+int ddpmir_ddrm_sample_loop(ddpmir_ctx* ctx, const float* y, float* out, int B, int H, int W, int quality,
+                            int steps, float eta, float eta_b, const ddpmir_loop_opts* opts);
+
+/* eps-predict DDPM flavour.  replaces: ddpm_inference(model, x0, T)  (experiments/code/conv.ipynb c1:117-125)
+ * on a context created with ddpmir_create_eps_unet(); x in [0,1], betas_host: float32[T_total].  Blocking. */
+ddpmir_ctx* ddpmir_create_eps_unet(int device);
+int ddpmir_predict_noise(ddpmir_ctx* ctx, const float* x, float t, float* eps, int B, int H, int W);
+int ddpmir_p_sample_loop(ddpmir_ctx* ctx, const float* x, float* out, int B, int H, int W, int T,
+                         const float* betas_host, int n_betas);
+
+/* standalone pieces, exported for the harness and for parity tests */
+int ddpmir_phase_consistency(ddpmir_ctx* ctx, const float* x, const float* ref, float* out, int B, int H, int W,
+                             float alpha);
+int ddpmir_jpeg_roundtrip_u8(ddpmir_ctx* ctx, const uint8_t* in_u8_nchw, uint8_t* out_u8_nchw, int B, int H, int W,
+                             int quality);   /* device pointers; bit-exact libjpeg-turbo simulator */
+
+/* timing of the last forward: per-kernel-class HIP-event milliseconds, for bench.py's roofline block */
+int ddpmir_last_forward_ms(ddpmir_ctx* ctx, float* total_ms);
+const char* ddpmir_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDPMIR_H */

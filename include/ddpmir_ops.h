@@ -1,0 +1,56 @@
+/*
+ * ddpmir_ops.h -- single-operator entry points of libddpmir.so on HOST buffers (the library stages them
+ * through the GPU).  They exist so every row of the hot-path table can be checked
+ * against the oracle in isolation; the product path is ddpmir.h.  All tensors fp32, NHWC unless noted.
+ * Each returns 0 or a negative DDPMIR_E* code; message via ddpmir_ops_last_error().
+ */
+#ifndef DDPMIR_OPS_H
+#define DDPMIR_OPS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* ddpmir_ops_last_error(void);
+
+/* nn.Conv2d 3x3 pad 1 / 1x1 / nn.Linear as implicit GEMM (webp_inference.py:282,292,229,215).
+ * x: [B,H,W,Cin] NHWC; w_oihw: torch layout [Cout][Cin][k][k]; bias [Cout] or NULL.
+ * Optional prologue: per-(b,c) scale/shift [B][Cin] then pro_act (0 none,1 gelu,2 silu), pro_mask (0,1 low,2 high).
+ * Optional epilogue: tb [B][Cout]; epi_act (0..6); mul [B,H,W,Cout]; rowscale [B]; epi_mask; res [B,H,W,Cout].
+ * out: [B,H,W,Cout] NHWC or [B,Cout,H,W] if nchw_out. */
+int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
+                   int ksize, const float* scale, const float* shift, int pro_act, int pro_mask, int bs, int low,
+                   const float* tb, int epi_act, const float* mul, const float* rowscale, int epi_mask,
+                   const float* res, int nchw_out, float* out);
+
+/* nn.GroupNorm statistics folded to per-(b,c) scale/shift (webp_inference.py:281); x [B,HW,C]. */
+int ddpmir_op_gn_scale_shift(const float* x, int B, int HW, int C, int G, const float* gamma, const float* beta,
+                             float* scale, float* shift);
+
+/* attention core on qkv [B,N,3C] -> out [B,N,C] (webp_inference.py:319) */
+int ddpmir_op_attention(const float* qkv, int B, int N, int C, int heads, float* out);
+
+/* blockwise T X T^T (DCTLayer webp_inference.py:161-192 / AVIFAdaptiveTransform avif_inference.py:140-177) */
+int ddpmir_op_block_transform(const float* x, int B, int H, int W, int C, int bs, const float* mats, int per_channel,
+                              float mix_in, float mix_t, float* out);
+
+int ddpmir_op_maxpool2(const float* x, int B, int H, int W, int C, float* out);        /* webp_inference.py:342 */
+int ddpmir_op_upsample2(const float* x, int B, int H, int W, int C, float* out);       /* webp_inference.py:389 */
+int ddpmir_op_bilinear(const float* x, int B, int Hi, int Wi, int C, int Ho, int Wo, float* out);
+int ddpmir_op_adaptive_avgpool(const float* x, int B, int H, int W, int C, int S, float* out);
+
+/* TimeEmbedding.forward (webp_inference.py:145-151): t [B] -> temb [B,256] */
+int ddpmir_op_time_embed(const float* t, int B, const float* w0, const float* b0, const float* w2, const float* b2,
+                         float* temb);
+
+/* uint8 quantisation (webp_inference.py:509) and one DDRM update (webp_inference.py:584-600) on NCHW images */
+int ddpmir_op_quantize_u8(const float* x, int64_t n, uint8_t* out);
+int ddpmir_op_ddrm_update(const float* x_theta, const uint8_t* dec_u8, const float* y, const float* noise,
+                          int64_t n_per_image, int B, float eta, float eta_b, float noise_coeff, int step_i, int steps,
+                          float* out);
+int ddpmir_op_randn(int64_t n, uint64_t seed, uint64_t offset, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,143 @@
+"""Whole-path parity on the GPU through the C ABI: U-Net forward and DDRM loop against the golden vectors
+produced by the reference (tests/golden) and against the numpy oracle at sizes the goldens do not hold."""
+import numpy as np
+import pytest
+
+from ddpm_image_restoration_amd import spec, synth
+from oracle import ddpm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ARCHS = [("webp", spec.ARCH_WEBP), ("jpeg", spec.ARCH_JPEG), ("avif", spec.ARCH_AVIF)]
+TOL = 1e-3   # north_star: max-abs pixel error within 1e-3 in fp32
+
+
+@pytest.fixture(scope="module")
+def models(synth_state):
+    import torch
+    from ddpm_image_restoration_amd.model import MODEL_BY_ARCH
+    cache = {}
+
+    def get(arch, **kw):
+        key = (arch, tuple(sorted(kw.items())))
+        if key not in cache:
+            m = MODEL_BY_ARCH[arch](device=torch.device("cuda", 0), **kw)
+            m.load_state_dict(synth_state(arch))
+            cache[key] = m
+        return cache[key]
+
+    return get
+
+
+def tt(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("name,arch", ARCHS)
+def test_forward_golden_32(name, arch, golden, models):
+    g = golden(name)
+    m = models(arch)
+    y = m(tt(g["fwd32_x"]), tt(g["fwd32_t"]), tt(g["fwd32_cl"])).cpu().numpy()
+    err = np.abs(y - g["fwd32_y"]).max()
+    assert err < TOL, err
+    assert m.param_count() == spec.param_count(arch)
+
+
+@pytest.mark.parametrize("name,arch", ARCHS)
+def test_forward_golden_64_and_nonsquare(name, arch, golden, models):
+    g = golden(name)
+    m = models(arch)
+    y = m(tt(g["fwd64_x"]), tt(g["fwd64_t"]), tt(g["fwd64_t"])).cpu().numpy()
+    assert np.abs(y - g["fwd64_y"]).max() < TOL
+    y = m(tt(g["fwd96_x"]), tt(g["fwd64_t"]), None).cpu().numpy()       # compression_level=None -> t
+    assert np.abs(y - g["fwd96_y"]).max() < TOL
+
+
+@pytest.mark.parametrize("name,arch", ARCHS)
+def test_forward_graph_replay_matches_eager(name, arch, golden, models):
+    g = golden(name)
+    y0 = models(arch)(tt(g["fwd32_x"]), tt(g["fwd32_t"]), tt(g["fwd32_cl"])).cpu().numpy()
+    mg = models(arch, use_graph=True)
+    for _ in range(3):   # capture, then two replays
+        y1 = mg(tt(g["fwd32_x"]), tt(g["fwd32_t"]), tt(g["fwd32_cl"])).cpu().numpy()
+    assert np.array_equal(y0, y1)
+
+
+@pytest.mark.parametrize("name,arch", ARCHS)
+def test_sampler_teacher_forced_golden(name, arch, golden, models):
+    g = golden(name)
+    m = models(arch)
+    steps, b = int(g["samp_steps"]), g["samp_y"].shape[0]
+    for i in g["samp_keep"]:
+        t = (np.full((b,), int(i), np.float32) / np.float32(steps)).astype(np.float32)
+        th = m(tt(g[f"samp_xt_in_{int(i)}"]), tt(t), tt(t)).cpu().numpy()
+        assert np.abs(th - g[f"samp_theta_{int(i)}"]).max() < TOL, int(i)
+
+
+@pytest.mark.parametrize("name,arch", ARCHS)
+def test_sampler_end_to_end_golden(name, arch, golden, models):
+    """Full trajectory with injected noise and the host codec callback: PSNR equal to 2 decimals, pixels
+    within 1e-3 except where a uint8 truncation flipped (reported, must be rare)."""
+    from ddpm_image_restoration_amd.sampler import SAMPLER_BY_ARCH
+    g = golden(name)
+    m = models(arch)
+    steps, q, b = int(g["samp_steps"]), int(g["samp_q"]), g["samp_y"].shape[0]
+    noise = synth.synth_noise(steps, b, 32, 32, seed=7)
+    out, tr = SAMPLER_BY_ARCH[arch](m).sample(tt(g["samp_y"]), q, steps=steps, noise=tt(noise), trace=True,
+                                              device_codec=False)
+    out, tr = out.cpu().numpy(), tr.cpu().numpy()
+    first = steps - 1
+    assert np.abs(tr[0, 0] - g[f"samp_theta_{first}"]).max() < TOL
+    x0 = g["samp_x0"]
+    assert round(O.psnr(out, x0), 2) == round(O.psnr(g["samp_final"], x0), 2)
+    flipped = float(np.mean(np.abs(out - g["samp_final"]) > TOL))
+    assert flipped < 0.01, flipped
+    # q50 run: no phase fix, JPEG 4:4:4
+    steps2, q2 = int(g["samp2_steps"]), int(g["samp2_q"])
+    n2 = synth.synth_noise(steps2, 2, 32, 32, seed=8)
+    out2 = SAMPLER_BY_ARCH[arch](m).sample(tt(g["samp2_y"]), q2, steps=steps2, noise=tt(n2), device_codec=False).cpu().numpy()
+    assert float(np.mean(np.abs(out2 - g["samp2_final"]) > TOL)) < 0.01
+
+
+@pytest.mark.parametrize("name,arch", ARCHS)
+def test_phase_consistency_golden(name, arch, golden, models):
+    from ddpm_image_restoration_amd.sampler import phase_consistency
+    g = golden(name)
+    alpha = O.SAMPLER[arch][3]
+    out = phase_consistency(models(arch), tt(g["pc_x"]), tt(g["pc_ref"]), alpha).cpu().numpy()
+    assert np.abs(out - g["pc_out"]).max() < 1e-5
+
+
+def test_forward_vs_oracle_128_bottleneck_attention(models, synth_state):
+    """attn_levels='bottleneck' variant (BASELINE configs 2-5) at 128x128 against the oracle with the same switch."""
+    x = synth.synth_images(1, 128, seed=77)
+    t = np.array([0.25], np.float32)
+    ref = O.Model(spec.ARCH_JPEG, synth_state(spec.ARCH_JPEG), attn_min_level=5)(x, t, t)
+    y = models(spec.ARCH_JPEG, attn_levels="bottleneck")(tt(x), tt(t), tt(t)).cpu().numpy()
+    assert np.abs(y - ref).max() < TOL
+
+
+def test_sampler_philox_shard_independent(models):
+    """Device RNG: sampling images [0:4) as one batch or as two shards of 2 gives identical results
+    (noise keyed by global image index) -- the property the multi-GPU split relies on."""
+    from ddpm_image_restoration_amd.sampler import DDRMWebPSampler
+    m = models(spec.ARCH_WEBP)
+    y = tt(synth.synth_images(4, 32, seed=5))
+    s = DDRMWebPSampler(m)
+    full = s.sample(y, 50, steps=4, seed=11).cpu().numpy()
+    a = s.sample(y[:2], 50, steps=4, seed=11, image_offset=0).cpu().numpy()
+    b = s.sample(y[2:], 50, steps=4, seed=11, image_offset=2).cpu().numpy()
+    assert np.array_equal(full, np.concatenate([a, b]))
+
+
+def test_error_paths(models):
+    import torch
+    from ddpm_image_restoration_amd.model import WebPDiffusionModel
+    m = WebPDiffusionModel(device=torch.device("cuda", 0))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 32).cuda(), torch.zeros(1).cuda())        # weights not loaded
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"bogus": np.zeros(3, np.float32)})
+    with pytest.raises(RuntimeError):
+        models(spec.ARCH_WEBP)(torch.zeros(1, 3, 40, 40).cuda(), torch.zeros(1).cuda())   # not a multiple of 32

@@ -1,0 +1,211 @@
+"""Per-operator parity: every HIP kernel on the hot path against the numpy oracle (rows a1-a13 of
+SURVEY.md section 8a).  fp32 tolerance 1e-4 relative to the output scale unless an op is bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import ddpm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ddpm_image_restoration_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def nhwc(x):
+    return np.ascontiguousarray(x.transpose(0, 2, 3, 1))
+
+
+def nchw(x):
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2))
+
+
+def close(a, b, tol=1e-4):
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, f"max err {err} (scale {scale})"
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [
+    (2, 16, 16, 64, 128, 3), (1, 32, 32, 3, 64, 3), (3, 8, 8, 128, 64, 3), (2, 4, 4, 512, 256, 3),
+    (4, 1, 1, 512, 1024, 3), (2, 2, 2, 1024, 512, 3), (1, 12, 20, 64, 3, 3), (2, 16, 16, 128, 384, 1),
+    (2, 16, 16, 64, 32, 1), (1, 6, 10, 256, 96, 1), (5, 7, 3, 36, 40, 3)])
+def test_conv_plain(ops, B, H, W, Cin, Cout, k):
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=1.0 / np.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=3)
+    ref = O.conv2d(x, w, b, k // 2)
+    got = ops.conv(nhwc(x), w, b)
+    close(nchw(got), ref)
+
+
+def test_conv_fused_norm_gelu_timebias_residual(ops):
+    """conv2 of a block: GroupNorm -> GELU applied in the loader, bias + time bias + residual in the epilogue."""
+    B, H, W, C, Co = 2, 16, 16, 64, 128
+    x = rnd(B, C, H, W, seed=4, scale=2.0) + 0.5
+    gamma, beta = rnd(C, seed=5) * 0.2 + 1, rnd(C, seed=6) * 0.1
+    w, b = rnd(Co, C, 3, 3, seed=7, scale=0.05), rnd(Co, seed=8)
+    tb, res = rnd(B, Co, seed=9), rnd(B, Co, H, W, seed=10)
+    ref = O.conv2d(O.gelu(O.group_norm(x, 8, gamma, beta)), w, b, 1) + tb[:, :, None, None] + res
+    sc, sh = ops.gn_scale_shift(nhwc(x), 8, gamma, beta)
+    got = ops.conv(nhwc(x), w, b, scale=sc, shift=sh, pro_act="gelu", tb=tb, res=nhwc(res))
+    close(nchw(got), ref)
+
+
+@pytest.mark.parametrize("C,G,HW", [(3, 3, 1024), (64, 8, 4096), (128, 8, 256), (1024, 8, 1), (512, 8, 4), (64, 8, 9000)])
+def test_group_norm_scale_shift(ops, C, G, HW):
+    x = rnd(2, C, HW, 1, seed=11, scale=3.0) + 1.5
+    gamma, beta = rnd(C, seed=12) * 0.2 + 1, rnd(C, seed=13) * 0.1
+    ref = O.group_norm(x, G, gamma, beta)
+    sc, sh = ops.gn_scale_shift(nhwc(x), G, gamma, beta)
+    got = x * sc[:, :, None, None] + sh[:, :, None, None]
+    close(got, ref, 2e-5)
+
+
+@pytest.mark.parametrize("act", ["silu", "gelu"])
+def test_conv_head_nchw_tanh(ops, act):
+    B, H, W, C = 2, 8, 8, 64
+    x = rnd(B, C, H, W, seed=14)
+    gamma, beta = np.ones(C, np.float32), np.zeros(C, np.float32)
+    w, b = rnd(3, C, 3, 3, seed=15, scale=0.05), rnd(3, seed=16)
+    f = O.silu if act == "silu" else O.gelu
+    ref = np.tanh(O.conv2d(f(O.group_norm(x, 8, gamma, beta)), w, b, 1))
+    sc, sh = ops.gn_scale_shift(nhwc(x), 8, gamma, beta)
+    got = ops.conv(nhwc(x), w, b, scale=sc, shift=sh, pro_act=act, epi_act="tanh", nchw_out=True)
+    close(got, ref, 2e-5)
+
+
+@pytest.mark.parametrize("H,W,bs,low", [(16, 16, 4, 3), (16, 16, 8, 4), (2, 2, 4, 3), (1, 1, 8, 4), (4, 4, 8, 4), (6, 10, 4, 3)])
+def test_frequency_gates(ops, H, W, bs, low):
+    """low/high gate pair of the frequency block (a8): masks in the GEMM loader and epilogue."""
+    B, C = 2, 64
+    xd = rnd(B, C, H, W, seed=17)
+    base = rnd(B, C, H, W, seed=18)
+    w1, b1 = rnd(C // 2, C, 1, 1, seed=19, scale=0.1), rnd(C // 2, seed=20)
+    w2, b2 = rnd(C, C // 2, 1, 1, seed=21, scale=0.1), rnd(C, seed=22)
+    boost = np.array([0.3, 1.7], np.float32)
+    m = O.low_mask(H, W, bs, low)[None, None]
+    for which, mask in (("low", m), ("high", ~m)):
+        z = np.where(mask, xd, 0).astype(np.float32)
+        hmid = O.conv2d(z, w1, b1, 0)
+        hmid = np.where(hmid > 0, hmid, 0.2 * hmid).astype(np.float32)
+        gate = O.sigmoid(O.conv2d(hmid, w2, b2, 0))
+        if which == "high":
+            gate = gate * boost[:, None, None, None]
+        ref = base + gate * z
+        hid = ops.conv(nhwc(xd), w1, b1, pro_mask=which, bs=bs, low=low, epi_act="lrelu")
+        got = ops.conv(hid, w2, b2, epi_act="sigmoid", mul=nhwc(xd), epi_mask=which, bs=bs, low=low,
+                       rowscale=boost if which == "high" else None, res=nhwc(base))
+        close(nchw(got), ref, 2e-5)
+
+
+@pytest.mark.parametrize("N,C,heads", [(256, 64, 4), (1024, 64, 4), (256, 128, 4), (64, 256, 4), (64, 512, 4),
+                                       (16, 512, 4), (4, 1024, 4), (1, 1024, 4), (96, 64, 8), (200, 128, 8),
+                                       (64, 1024, 8), (4, 1024, 8)])
+def test_attention(ops, N, C, heads):
+    B = 2
+    qkv = rnd(B, N, 3 * C, seed=23, scale=1.5)
+    d = C // heads
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    sp = lambda z: z.reshape(B, N, heads, d).transpose(0, 2, 1, 3)
+    s = (sp(q) / np.sqrt(d)) @ sp(k).transpose(0, 1, 3, 2)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ sp(v)).transpose(0, 2, 1, 3).reshape(B, N, C)
+    got = ops.attention(qkv, heads)
+    close(got, ref, 2e-5)
+
+
+def test_attention_spiky_softmax(ops):
+    """a query/key pair with a huge score forces the online-softmax rescale path mid-sequence."""
+    B, N, C, heads = 1, 512, 64, 4
+    qkv = rnd(B, N, 3 * C, seed=24)
+    qkv[0, 5, :16] *= 30
+    qkv[0, 300, C:C + 16] = qkv[0, 5, :16]
+    d = C // heads
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    sp = lambda z: z.reshape(B, N, heads, d).transpose(0, 2, 1, 3).astype(np.float64)
+    s = (sp(q) / np.sqrt(d)) @ sp(k).transpose(0, 1, 3, 2)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ sp(v)).transpose(0, 2, 1, 3).reshape(B, N, C)
+    close(ops.attention(qkv, heads), ref.astype(np.float32), 2e-5)
+
+
+@pytest.mark.parametrize("H,W,bs", [(16, 16, 4), (16, 16, 8), (2, 2, 4), (1, 1, 8), (4, 4, 8), (6, 10, 4), (12, 20, 8)])
+def test_block_dct(ops, H, W, bs):
+    from ddpm_image_restoration_amd.synth import dct_matrix
+    x = rnd(2, 64, H, W, seed=25)
+    D = dct_matrix(bs)
+    close(nchw(ops.block_transform(nhwc(x), D)), O.blockwise_transform(x, D), 1e-5)
+    close(nchw(ops.block_transform(nhwc(x), D, 1.0, 0.1)), x + np.float32(0.1) * O.blockwise_transform(x, D), 1e-5)
+
+
+def test_block_transform_per_channel(ops):
+    x = rnd(2, 32, 12, 20, seed=26)
+    T = rnd(32, 8, 8, seed=27, scale=0.35)
+    close(nchw(ops.block_transform(nhwc(x), T)), O.blockwise_transform(x, T), 1e-5)
+
+
+def test_pool_and_resample(ops):
+    x = rnd(2, 64, 12, 20, seed=28)
+    assert np.array_equal(nchw(ops.maxpool2(nhwc(x))), O.max_pool2(x))
+    close(nchw(ops.upsample2(nhwc(x))), O.upsample2(x), 1e-6)
+    for s in (1, 2, 4, 8):
+        close(nchw(ops.adaptive_avgpool(nhwc(x), s)), O.adaptive_avg_pool(x, s), 1e-6)
+    small = rnd(2, 64, 2, 2, seed=29)
+    for s in (1, 2, 4, 8):
+        a = O.adaptive_avg_pool(small, s)
+        close(nchw(ops.adaptive_avgpool(nhwc(small), s)), a, 1e-6)
+        close(nchw(ops.bilinear(nhwc(a), 2, 2)), O.bilinear(a, 2, 2), 1e-6)
+    a8 = O.adaptive_avg_pool(x, 8)
+    close(nchw(ops.bilinear(nhwc(a8), 12, 20)), O.bilinear(a8, 12, 20), 1e-6)
+
+
+def test_time_embedding(ops, synth_state):
+    sd = synth_state(0)
+    t = np.array([0.0, 0.37, 0.999, 0.5], np.float32)
+    m = O.Model(0, sd)
+    ref = m.time_embedding(t)
+    got = ops.time_embed(t, sd["time_embed.proj.0.weight"], sd["time_embed.proj.0.bias"],
+                         sd["time_embed.proj.2.weight"], sd["time_embed.proj.2.bias"])
+    close(got, ref, 1e-5)
+
+
+def test_quantize_bit_exact(ops):
+    x = np.concatenate([rnd(100000, seed=30, scale=0.7), np.linspace(-1.2, 1.2, 50001, dtype=np.float32),
+                        ((np.arange(256, dtype=np.float32) - 127.5) / 127.5).astype(np.float32)])
+    assert np.array_equal(ops.quantize_u8(x), O.to_u8(x))
+
+
+def test_ddrm_update_bit_exact(ops):
+    B, n = 3, 3 * 32 * 32
+    th, y, nz = rnd(B, n, seed=31, scale=0.5), rnd(B, n, seed=32, scale=0.5), rnd(B, n, seed=33)
+    dec = np.random.default_rng(34).integers(0, 256, (B, n), dtype=np.uint8)
+    for eta_b in (1.0, 0.6):
+        for i, steps in ((7, 50), (0, 50), (999, 1000)):
+            t = np.float32(i) / np.float32(steps)
+            xp = (th - O.from_u8(dec)) + y
+            if i > 0:
+                rn = nz * (t * np.float32(0.2))
+                ref = (np.float32(eta_b) * xp + np.float32(1 - eta_b) * th) + np.float32(0.85) * rn
+            else:
+                ref = xp
+            got = ops.ddrm_update(th, dec, y, nz, 0.85, eta_b, 0.2, i, steps)
+            assert np.array_equal(got, ref.astype(np.float32)), (eta_b, i)
+
+
+def test_randn_moments_and_shard_independence(ops):
+    a = ops.randn(1 << 20, seed=7)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
+    assert abs(float((a ** 4).mean()) - 3) < 0.05
+    b = ops.randn(1 << 19, seed=7, offset=(1 << 19) // 4)
+    assert np.array_equal(a[1 << 19:], b)       # second half drawn as its own shard: same numbers
