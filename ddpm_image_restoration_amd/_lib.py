@@ -18,8 +18,9 @@ class Config(C.Structure):
 
 class LoopOpts(C.Structure):
     _fields_ = [("codec", CODEC_FN), ("codec_user", C.c_void_p), ("noise", C.c_void_p), ("seed", C.c_uint64),
-                ("image_offset", C.c_uint64), ("trace", C.c_void_p), ("noise_coeff", C.c_float),
-                ("phase_q", C.c_int), ("phase_every", C.c_int), ("phase_alpha", C.c_float)]
+                ("image_offset", C.c_uint64), ("trace", C.c_void_p), ("noise_coeff", C.c_double),
+                ("phase_q", C.c_int), ("phase_every", C.c_int), ("phase_alpha", C.c_double),
+                ("start_step", C.c_int), ("num_steps", C.c_int)]
 
 
 # every symbol include/ddpmir.h declares: name -> (restype, argtypes)
@@ -34,19 +35,34 @@ SYMBOLS = {
     "ddpmir_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_void_p]),
     "ddpmir_ddrm_sample_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                          C.c_int, C.c_float, C.c_float, C.POINTER(LoopOpts)]),
+                                          C.c_int, C.c_double, C.c_double, C.POINTER(LoopOpts)]),
     "ddpmir_create_eps_unet": (C.c_void_p, [C.c_int]),
     "ddpmir_predict_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "ddpmir_p_sample_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_int]),
     "ddpmir_phase_consistency": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                           C.c_float]),
+                                           C.c_double]),
     "ddpmir_jpeg_roundtrip_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "ddpmir_last_forward_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "ddpmir_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddpmir_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_double)]),
     "ddpmir_version": (C.c_char_p, []),
 }
 
 _lib = None
+
+
+def _preload_hip_runtime():
+    """libddpmir.so takes device pointers from torch tensors, so both must sit on ONE HIP runtime.  The torch
+    wheel bundles its own libamdhip64 (same SONAME as /opt/rocm's): load that copy first so the dynamic linker
+    binds libddpmir.so's libamdhip64.so.7 dependency to it instead of opening a second runtime."""
+    try:
+        import torch
+    except ImportError:
+        return   # standalone use: the system ROCm runtime is picked up through DT_NEEDED
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
 def load() -> C.CDLL:
@@ -58,6 +74,7 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc, gfx950).  There is no CPU fallback for the restoration path.")
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the export is missing

@@ -93,7 +93,7 @@ int ddpmir_predict(ddpmir_ctx* ctx, const float* x, const float* t, const float*
 }
 
 int ddpmir_ddrm_sample_loop(ddpmir_ctx* ctx, const float* y, float* out, int B, int H, int W, int quality, int steps,
-                            float eta, float eta_b, const ddpmir_loop_opts* opts) {
+                            double eta, double eta_b, const ddpmir_loop_opts* opts) {
   return guarded(ctx, [&] {
     if (!y || !out) throw std::invalid_argument("sample: null pointer");
     ctx->impl->ddrm_sample_loop(y, out, B, H, W, quality, steps, eta, eta_b, opts);
@@ -101,15 +101,22 @@ int ddpmir_ddrm_sample_loop(ddpmir_ctx* ctx, const float* y, float* out, int B, 
 }
 
 int ddpmir_phase_consistency(ddpmir_ctx* ctx, const float* x, const float* ref, float* out, int B, int H, int W,
-                             float alpha) {
+                             double alpha) {
   return guarded(ctx, [&] {
     if (!x || !ref || !out) throw std::invalid_argument("phase_consistency: null pointer");
     ctx->impl->phase_consistency(x, ref, out, B, H, W, alpha);
   });
 }
 
-int ddpmir_last_forward_ms(ddpmir_ctx* ctx, float* total_ms) {
-  return guarded(ctx, [&] { if (total_ms) *total_ms = ctx->impl->last_forward_ms; });
+int ddpmir_profile_enable(ddpmir_ctx* ctx, int enable) {
+  return guarded(ctx, [&] { ctx->impl->profile_enable(enable); });
+}
+
+int ddpmir_profile_read(ddpmir_ctx* ctx, const char* cls, double* ms, int64_t* launches, double* flops) {
+  return guarded(ctx, [&] {
+    if (!cls) throw std::invalid_argument("profile_read: null class");
+    ctx->impl->profile_read(cls, ms, launches, flops);
+  });
 }
 
 const char* ddpmir_version(void) { return "ddpmir 0.1.0 (gfx950)"; }

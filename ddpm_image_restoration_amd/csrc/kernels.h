@@ -101,7 +101,7 @@ void launch_unit_phase(float* re, float* im, int64_t n, hipStream_t s);
 // out = alpha*x + (1-alpha) * Re(ifft2(|X| * U))   (X = re/im in, U = unit phase)
 void launch_phase_apply_inverse(const float* x, const float* xre, const float* xim, const float* ure,
                                 const float* uim, float* tmp_re, float* tmp_im, float* tmp2_re, float* tmp2_im,
-                                float* out, int P, const DftPlan& d, float alpha, hipStream_t s);
+                                float* out, int P, const DftPlan& d, float alpha, float one_minus_alpha, hipStream_t s);
 
 // eps-DDPM posterior mean step (conv.ipynb c1:124): x = c1 * (x - c2 * eps)
 void launch_axpby(const float* x, const float* e, float* out, float c1, float c2, int64_t n, hipStream_t s);

@@ -76,10 +76,11 @@ class Context {
   int64_t param_count() const { return n_params_; }
 
   void predict(const float* x, const float* t, const float* cl, float* out, int B, int H, int W, hipStream_t s);
-  void ddrm_sample_loop(const float* y, float* out, int B, int H, int W, int quality, int steps, float eta,
-                        float eta_b, const ddpmir_loop_opts* opts);
-  void phase_consistency(const float* x, const float* ref, float* out, int B, int H, int W, float alpha);
-  float last_forward_ms = 0.f;
+  void ddrm_sample_loop(const float* y, float* out, int B, int H, int W, int quality, int steps, double eta,
+                        double eta_b, const ddpmir_loop_opts* opts);
+  void phase_consistency(const float* x, const float* ref, float* out, int B, int H, int W, double alpha);
+  void profile_enable(int enable);
+  void profile_read(const std::string& cls, double* ms, int64_t* launches, double* flops);
 
  private:
   // ---- weights
@@ -135,6 +136,17 @@ class Context {
   void conv(const ConvW& cw, IGemm p, hipStream_t s);
   void phase_fix(float* x, int B, int H, int W, double alpha, hipStream_t s);   // uses cached unit phase of y
   void phase_prepare(const float* y, int B, int H, int W, hipStream_t s);
+
+  // ---- HIP-event profiling of kernel classes
+  struct ProfSpan { hipEvent_t a, b; int cls; double flops; };
+  std::vector<ProfSpan> prof_spans_;
+  std::vector<hipEvent_t> prof_pool_;
+  bool prof_on_ = false;
+  double prof_ms_[3] = {0, 0, 0}; int64_t prof_n_[3] = {0, 0, 0}; double prof_flops_[3] = {0, 0, 0};
+  hipEvent_t prof_event();
+  void prof_begin(int cls, double flops, hipStream_t s);
+  void prof_end(hipStream_t s);
+  void prof_collect();
 
   hipStream_t stream_ = nullptr;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;

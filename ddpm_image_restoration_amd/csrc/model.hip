@@ -51,6 +51,8 @@ Context::~Context() {
   if (wblob_ && wblob_owned_) (void)hipFree(wblob_);
   if (pin_in_) (void)hipHostFree(pin_in_);
   if (pin_out_) (void)hipHostFree(pin_out_);
+  for (auto& sp : prof_spans_) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  for (auto e : prof_pool_) (void)hipEventDestroy(e);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -299,6 +301,54 @@ void Context::ensure_plan(int B, int H, int W) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ profiling
+enum { PROF_ATTN_L0 = 0, PROF_ATTN = 1, PROF_FWD = 2 };
+
+hipEvent_t Context::prof_event() {
+  if (!prof_pool_.empty()) { hipEvent_t e = prof_pool_.back(); prof_pool_.pop_back(); return e; }
+  hipEvent_t e;
+  DDPMIR_HIP_CHECK(hipEventCreate(&e));
+  return e;
+}
+void Context::prof_begin(int cls, double flops, hipStream_t s) {
+  if (!prof_on_) return;
+  ProfSpan sp{prof_event(), prof_event(), cls, flops};
+  DDPMIR_HIP_CHECK(hipEventRecord(sp.a, s));
+  prof_spans_.push_back(sp);
+}
+void Context::prof_end(hipStream_t s) {
+  if (!prof_on_) return;
+  DDPMIR_HIP_CHECK(hipEventRecord(prof_spans_.back().b, s));
+}
+void Context::prof_collect() {
+  for (auto& sp : prof_spans_) {
+    DDPMIR_HIP_CHECK(hipEventSynchronize(sp.b));
+    float ms = 0.f;
+    DDPMIR_HIP_CHECK(hipEventElapsedTime(&ms, sp.a, sp.b));
+    prof_ms_[sp.cls] += ms; prof_n_[sp.cls] += 1; prof_flops_[sp.cls] += sp.flops;
+    if (sp.cls == PROF_ATTN_L0) { prof_ms_[PROF_ATTN] += ms; prof_n_[PROF_ATTN] += 1; prof_flops_[PROF_ATTN] += sp.flops; }
+    prof_pool_.push_back(sp.a); prof_pool_.push_back(sp.b);
+  }
+  prof_spans_.clear();
+}
+void Context::profile_enable(int enable) {
+  DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
+  if (enable) {
+    if (cfg.use_graph) throw std::logic_error("profiling needs use_graph = 0 (events cannot bracket nodes of a replayed graph)");
+    prof_collect();
+    for (int i = 0; i < 3; ++i) { prof_ms_[i] = 0; prof_n_[i] = 0; prof_flops_[i] = 0; }
+  }
+  prof_on_ = enable != 0;
+}
+void Context::profile_read(const std::string& cls, double* ms, int64_t* launches, double* flops) {
+  prof_collect();
+  int c = cls == "attention_l0" ? PROF_ATTN_L0 : cls == "attention" ? PROF_ATTN : cls == "forward" ? PROF_FWD : -1;
+  if (c < 0) throw std::invalid_argument("unknown profile class " + cls);
+  if (ms) *ms = prof_ms_[c];
+  if (launches) *launches = prof_n_[c];
+  if (flops) *flops = prof_flops_[c];
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 void Context::conv(const ConvW& cw, IGemm p, hipStream_t s) {
   p.Wt = cw.w; p.bias = cw.b; p.Cout = cw.cout; p.Cin = cw.cinp; p.taps = cw.taps;
@@ -389,7 +439,11 @@ void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int 
   if (bw.level >= cfg.attn_min_level) {
     IGemm q = g; q.A = p.hB; q.lda = C; q.out = p.qkv; q.ldo = 3 * C;
     conv(bw.in_proj, q, s);
+    // algorithmic FLOPs of QK^T + PV: 4 * N^2 * C per image
+    const double nn = (double)H * W;
+    prof_begin(bw.level == 0 ? PROF_ATTN_L0 : PROF_ATTN, 4.0 * nn * nn * C * B, s);
     launch_attention(p.qkv, p.att, C, B, H * W, C, k.heads, s);
+    prof_end(s);
     IGemm o = g; o.A = p.att; o.lda = C; o.res = p.hB; o.ldres = C; o.out = p.hB; o.ldo = C;
     conv(bw.out_proj, o, s);
   }
@@ -410,6 +464,7 @@ void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int 
 void Context::forward(const float* x, const float* t, const float* cl, float* out, hipStream_t s) {
   Plan& p = plan_;
   const int B = p.B, H = p.H, W = p.W;
+  prof_begin(PROF_FWD, 0.0, s);
   launch_nchw3_to_nhwc4(x, p.x4, B, H, W, s);
   launch_time_embed(t, B, tw_, p.hidden, p.temb, p.tproj, s);
   if (cfg.arch == DDPMIR_ARCH_AVIF) {
@@ -452,6 +507,10 @@ void Context::forward(const float* x, const float* t, const float* cl, float* ou
   IGemm hc; hc.B = B; hc.H = H; hc.W = W; hc.A = p.S; hc.lda = 64; hc.scale = p.sc1; hc.shift = p.sh1;
   hc.pro_act = ACT_SILU; hc.epi_act = ACT_TANH; hc.out = out; hc.ldo = 0; hc.store = STORE_NCHW;
   conv(head_conv_, hc, s);
+  if (prof_on_) {  // close the "forward" span (the attention spans nested inside are already closed)
+    for (auto it = prof_spans_.rbegin(); it != prof_spans_.rend(); ++it)
+      if (it->cls == PROF_FWD) { DDPMIR_HIP_CHECK(hipEventRecord(it->b, s)); break; }
+  }
 }
 
 void Context::predict(const float* x, const float* t, const float* cl, float* out, int B, int H, int W, hipStream_t s) {
@@ -504,10 +563,10 @@ void Context::phase_fix(float* x, int B, int H, int W, double alpha, hipStream_t
   const int P = B * 3;
   launch_dft2_forward(x, p.dft[2], p.dft[3], p.dft[4], p.dft[5], P, d, s);
   launch_phase_apply_inverse(x, p.dft[2], p.dft[3], p.dft[0], p.dft[1], p.dft[4], p.dft[5], p.dft[6], p.dft[7], x, P,
-                             d, (float)alpha, s);
+                             d, (float)alpha, (float)(1.0 - alpha), s);
 }
 
-void Context::phase_consistency(const float* x, const float* ref, float* out, int B, int H, int W, float alpha) {
+void Context::phase_consistency(const float* x, const float* ref, float* out, int B, int H, int W, double alpha) {
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
   ensure_plan(B, H, W);
   Plan& p = plan_;
@@ -520,8 +579,8 @@ void Context::phase_consistency(const float* x, const float* ref, float* out, in
 }
 
 // ------------------------------------------------------------------------------------------------ DDRM loop
-void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, int quality, int steps, float eta,
-                               float eta_b, const ddpmir_loop_opts* opts) {
+void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, int quality, int steps, double eta,
+                               double eta_b, const ddpmir_loop_opts* opts) {
   if (!finalized_) throw std::logic_error("sample before finalize_weights");
   if (steps <= 0) throw std::invalid_argument("steps must be positive");
   if (!opts || !opts->codec) throw std::invalid_argument("a codec callback is required (no built-in codec for this model family)");
@@ -530,18 +589,20 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
   Plan& p = plan_;
   hipStream_t s = stream_;
   const size_t n = (size_t)B * 3 * H * W;
-  const float coeff = opts->noise_coeff >= 0.f ? opts->noise_coeff : k.noise_coeff;
+  const float coeff = opts->noise_coeff >= 0.0 ? (float)opts->noise_coeff : k.noise_coeff;
   const int phase_q = opts->phase_q >= 0 ? opts->phase_q : k.phase_q;
   const int every = opts->phase_every > 0 ? opts->phase_every : k.phase_every;
-  const double alpha = opts->phase_alpha >= 0.f ? (double)opts->phase_alpha : k.phase_alpha;
-  const float one_minus_eta_b = (float)(1.0 - (double)eta_b);
+  const double alpha = opts->phase_alpha >= 0.0 ? opts->phase_alpha : k.phase_alpha;
+  const float one_minus_eta_b = (float)(1.0 - eta_b);   // Python forms (1 - eta_b) in double (webp_inference.py:592)
   const bool do_phase = quality < phase_q;
 
   DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_y, y, n * 4, hipMemcpyDeviceToDevice, s));     // y = x_t.clone()
   DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_xt, y, n * 4, hipMemcpyDeviceToDevice, s));
   if (do_phase) phase_prepare(p.s_y, B, H, W, s);
   const bool graph = cfg.use_graph != 0;
-  for (int i = steps - 1; i >= 0; --i) {
+  const int i_first = (opts->start_step >= 0 && opts->start_step < steps) ? opts->start_step : steps - 1;
+  const int i_last = opts->num_steps > 0 ? std::max(0, i_first - opts->num_steps + 1) : 0;
+  for (int i = i_first; i >= i_last; --i) {
     launch_fill_t(p.s_t, B, i, steps, s);
     if (graph) {
       predict(p.s_xt, p.s_t, p.s_t, p.s_theta, B, H, W, s);
@@ -564,11 +625,11 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
         noise = p.s_noise;
       }
     }
-    launch_ddrm_update(p.s_theta, p.s_dec, p.s_y, noise, p.s_xt, (int64_t)3 * H * W, B, eta, eta_b, one_minus_eta_b,
+    launch_ddrm_update(p.s_theta, p.s_dec, p.s_y, noise, p.s_xt, (int64_t)3 * H * W, B, (float)eta, (float)eta_b, one_minus_eta_b,
                        coeff, i, steps, i == 0 ? 1 : 0, s);
     if (i > 0 && do_phase && (i % every) == 0) phase_fix(p.s_xt, B, H, W, alpha, s);
     if (opts->trace) {
-      float* tr = opts->trace + (size_t)(steps - 1 - i) * 2 * n;
+      float* tr = opts->trace + (size_t)(i_first - i) * 2 * n;
       DDPMIR_HIP_CHECK(hipMemcpyAsync(tr, p.s_theta, n * 4, hipMemcpyDeviceToDevice, s));
       DDPMIR_HIP_CHECK(hipMemcpyAsync(tr + n, p.s_xt, n * 4, hipMemcpyDeviceToDevice, s));
     }

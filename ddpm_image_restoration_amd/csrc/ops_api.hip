@@ -197,14 +197,14 @@ int ddpmir_op_quantize_u8(const float* x, int64_t n, uint8_t* out) {
 }
 
 int ddpmir_op_ddrm_update(const float* x_theta, const uint8_t* dec_u8, const float* y, const float* noise,
-                          int64_t n_per_image, int B, float eta, float eta_b, float noise_coeff, int step_i, int steps,
+                          int64_t n_per_image, int B, double eta, double eta_b, double noise_coeff, int step_i, int steps,
                           float* out) {
   return guarded([&] {
     Dev d;
     size_t n = (size_t)n_per_image * B;
     float* o = d.alloc<float>(n);
-    launch_ddrm_update(d.up(x_theta, n), d.up(dec_u8, n), d.up(y, n), d.up(noise, n), o, n_per_image, B, eta, eta_b,
-                       (float)(1.0 - (double)eta_b), noise_coeff, step_i, steps, step_i == 0 ? 1 : 0, nullptr);
+    launch_ddrm_update(d.up(x_theta, n), d.up(dec_u8, n), d.up(y, n), d.up(noise, n), o, n_per_image, B, (float)eta,
+                       (float)eta_b, (float)(1.0 - eta_b), (float)noise_coeff, step_i, steps, step_i == 0 ? 1 : 0, nullptr);
     d.down(out, o, n);
   });
 }

@@ -4,6 +4,10 @@
 // 1-ulp difference there flips a pixel by 1/127.5 after the codec.
 #include "kernels.h"
 
+// hipcc defaults to -ffp-contract=fast and __fmul_rn/__fadd_rn are plain operators in the HIP headers, so
+// contraction has to be switched off for this translation unit (build.py also passes -ffp-contract=off).
+#pragma clang fp contract(off)
+
 namespace ddpmir {
 
 namespace {
@@ -219,7 +223,7 @@ void launch_unit_phase(float* re, float* im, int64_t n, hipStream_t s) {
 
 void launch_phase_apply_inverse(const float* x, const float* xre, const float* xim, const float* ure,
                                 const float* uim, float* tmp_re, float* tmp_im, float* tmp2_re, float* tmp2_im,
-                                float* out, int P, const DftPlan& d, float alpha, hipStream_t s) {
+                                float* out, int P, const DftPlan& d, float alpha, float one_minus_alpha, hipStream_t s) {
   const int H = d.H, W = d.W;
   const int64_t n = (int64_t)P * H * W;
   hipLaunchKernelGGL(mag_times_phase_k, dim3(grid_for(n)), dim3(256), 0, s, xre, xim, ure, uim, tmp_re, tmp_im, n);
@@ -228,9 +232,8 @@ void launch_phase_apply_inverse(const float* x, const float* xre, const float* x
                      tmp2_im, H, W, d.cos_h, d.sin_h, 1.0f, 1.0f / (float)H, 0);
   hipLaunchKernelGGL(dft_rows_k, dim3((unsigned)((size_t)P * H)), dim3(256), 4 * W * sizeof(float), s, tmp2_re,
                      tmp2_im, tmp_re, tmp_im, W, d.cos_w, d.sin_w, 1.0f, 1.0f / (float)W);
-  // python: alpha * x + (1 - alpha) * adjusted ; (1 - alpha) is evaluated in double then rounded to fp32
-  float beta = (float)(1.0 - (double)alpha);
-  hipLaunchKernelGGL(blend_k, dim3(grid_for(n)), dim3(256), 0, s, x, tmp_re, out, alpha, beta, n);
+  // python: alpha * x + (1 - alpha) * adjusted ; (1 - alpha) is evaluated in double by the caller
+  hipLaunchKernelGGL(blend_k, dim3(grid_for(n)), dim3(256), 0, s, x, tmp_re, out, alpha, one_minus_alpha, n);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

@@ -80,18 +80,20 @@ class _RestorationModel:
         if strict and (missing or unexpected):
             raise RuntimeError(f"state_dict mismatch: missing {missing[:5]}... unexpected {unexpected[:5]}...")
         for name in want:
-            if name not in state:
-                continue
-            v = state[name]
-            arr = v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, dtype=np.float32)
-            arr = np.ascontiguousarray(arr, dtype=np.float32)
-            if tuple(arr.shape) != tuple(want[name]):
-                raise RuntimeError(f"shape mismatch for {name}: {tuple(arr.shape)} vs {want[name]}")
-            shape = (C.c_int64 * arr.ndim)(*arr.shape)
-            rc = self._lib.ddpmir_load_tensor(self._ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim)
-            _lib.check(self._lib, self._ctx, rc, f"load_tensor({name})")
+            if name in state:
+                self._load_one(name, state[name])
         self.finalize()
         return self
+
+    def _load_one(self, name, v):
+        want = spec.state_spec(self.ARCH)
+        arr = v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, dtype=np.float32)
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        if name not in want or tuple(arr.shape) != tuple(want[name]):
+            raise RuntimeError(f"unexpected tensor or shape for {name}: {tuple(arr.shape)}")
+        shape = (C.c_int64 * arr.ndim)(*arr.shape)
+        rc = self._lib.ddpmir_load_tensor(self._ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim)
+        _lib.check(self._lib, self._ctx, rc, f"load_tensor({name})")
 
     def finalize(self, blob=None, fill: bool = True):
         """blob: optional torch uint8 CUDA tensor of weight_blob_bytes() bytes that will hold the packed weights
@@ -106,6 +108,16 @@ class _RestorationModel:
 
     def weight_blob_bytes(self) -> int:
         return int(self._lib.ddpmir_weight_blob_bytes(self._ctx))
+
+    def profile(self, enable: bool):
+        _lib.check(self._lib, self._ctx, self._lib.ddpmir_profile_enable(self._ctx, int(enable)), "profile_enable")
+
+    def profile_read(self, cls: str):
+        """(device ms, launches, algorithmic FLOPs) accumulated for a kernel class since profile(True)."""
+        ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+        rc = self._lib.ddpmir_profile_read(self._ctx, cls.encode(), C.byref(ms), C.byref(n), C.byref(fl))
+        _lib.check(self._lib, self._ctx, rc, "profile_read")
+        return ms.value, n.value, fl.value
 
     def param_count(self) -> int:
         return int(self._lib.ddpmir_param_count(self._ctx))

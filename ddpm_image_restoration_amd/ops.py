@@ -23,7 +23,7 @@ _sigs = {
     "ddpmir_op_adaptive_avgpool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ddpmir_op_time_embed": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "ddpmir_op_quantize_u8": (C.c_int, [_P, C.c_int64, _P]),
-    "ddpmir_op_ddrm_update": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
+    "ddpmir_op_ddrm_update": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                                         C.c_int, _P]),
     "ddpmir_op_randn": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, _P]),
 }

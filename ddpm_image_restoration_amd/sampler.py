@@ -38,7 +38,7 @@ class _DDRMSampler:
         return _lib.CODEC_FN(cb)
 
     def sample(self, x_t, quality, steps=100, eta=0.85, eta_b=1.0, noise=None, seed=0, image_offset=0,
-               trace=False, device_codec=None):
+               trace=False, device_codec=None, start_step=-1, num_steps=0):
         """noise: optional tensor [steps,B,3,H,W]; noise[i] replaces torch.randn_like at loop index i.
         trace=True additionally returns a [steps,2,B,3,H,W] tensor of (x_theta, x_t) per executed step."""
         import torch
@@ -49,7 +49,7 @@ class _DDRMSampler:
         out = torch.empty_like(x)
         opts = _lib.LoopOpts()
         cb = self._codec_cb()
-        use_dev = (self.KIND == "jpeg") if device_codec is None else bool(device_codec)
+        use_dev = bool(device_codec)
         opts.codec = _lib.CODEC_FN(0) if (use_dev and self.KIND == "jpeg") else cb
         opts.codec_user = None
         nz = None
@@ -62,12 +62,15 @@ class _DDRMSampler:
         opts.image_offset = int(image_offset)
         tr = None
         if trace:
-            tr = torch.empty((steps, 2, b, c, h, w), device=m.device, dtype=torch.float32)
+            tr = torch.empty((num_steps if num_steps > 0 else steps, 2, b, c, h, w), device=m.device,
+                             dtype=torch.float32)
             opts.trace = tr.data_ptr()
         opts.noise_coeff = -1.0
         opts.phase_q = -1
         opts.phase_every = 0
         opts.phase_alpha = -1.0
+        opts.start_step = int(start_step)
+        opts.num_steps = int(num_steps)
         torch.cuda.current_stream(m.device).synchronize()
         rc = self._lib.ddpmir_ddrm_sample_loop(m._ctx, x.data_ptr(), out.data_ptr(), b, h, w, int(quality), int(steps),
                                                float(eta), float(eta_b), C.byref(opts))

@@ -81,16 +81,21 @@ typedef struct ddpmir_loop_opts {
   uint64_t seed;
   uint64_t image_offset;      /* global index of image 0 of this shard (multi-GPU: results independent of N) */
   float* trace;               /* optional device pointer [steps][2][B][3][H][W]: x_theta, x_t after each step */
-  float noise_coeff;          /* <0 = the model family's default (0.2 / 0.15) */
+  double noise_coeff;         /* <0 = the model family's default (0.2 / 0.15) */
   int phase_q;                /* <0 = default quality threshold of the phase fix (15 / 20 / 30) */
   int phase_every;            /* <=0 = default (5 / 3) */
-  float phase_alpha;          /* <0 = default (0.7 / 0.8) */
+  double phase_alpha;         /* <0 = default (0.7 / 0.8) */
+  int start_step;             /* <0 = steps-1.  Run the loop from index i = start_step ... */
+  int num_steps;              /* <=0 = down to i = 0; else only this many iterations (bench.py times a slice of the
+                                 T-step schedule; x_t is then NOT a finished restoration) */
 } ddpmir_loop_opts;
 
 /* replaces: DDRM{WebP,JPEG,AVIF}Sampler(model).sample(x_t, quality, steps, eta, eta_b)
- * (webp_inference.py:557-602, avif_inference.py:414-459, svd.ipynb c0:395-440).  Blocking. */
+ * (webp_inference.py:557-602, avif_inference.py:414-459, svd.ipynb c0:395-440).  Blocking.
+ * eta / eta_b / alpha are doubles because the reference forms (1 - eta_b) and (1 - alpha) in Python double
+ * precision before the fp32 tensor multiply. */
 int ddpmir_ddrm_sample_loop(ddpmir_ctx* ctx, const float* y, float* out, int B, int H, int W, int quality,
-                            int steps, float eta, float eta_b, const ddpmir_loop_opts* opts);
+                            int steps, double eta, double eta_b, const ddpmir_loop_opts* opts);
 
 /* eps-predict DDPM flavour.  replaces: ddpm_inference(model, x0, T)  (experiments/code/conv.ipynb c1:117-125)
  * on a context created with ddpmir_create_eps_unet(); x in [0,1], betas_host: float32[T_total].  Blocking. */
@@ -101,12 +106,16 @@ int ddpmir_p_sample_loop(ddpmir_ctx* ctx, const float* x, float* out, int B, int
 
 /* standalone pieces, exported for the harness and for parity tests */
 int ddpmir_phase_consistency(ddpmir_ctx* ctx, const float* x, const float* ref, float* out, int B, int H, int W,
-                             float alpha);
+                             double alpha);
 int ddpmir_jpeg_roundtrip_u8(ddpmir_ctx* ctx, const uint8_t* in_u8_nchw, uint8_t* out_u8_nchw, int B, int H, int W,
                              int quality);   /* device pointers; bit-exact libjpeg-turbo simulator */
 
-/* timing of the last forward: per-kernel-class HIP-event milliseconds, for bench.py's roofline block */
-int ddpmir_last_forward_ms(ddpmir_ctx* ctx, float* total_ms);
+/* HIP-event timing of kernel classes on the context's stream (bench.py's roofline block).  enable=1 brackets
+ * every launch of the profiled classes with events; read returns the accumulated device milliseconds, launch
+ * count and algorithmic FLOPs since the last enable.  Classes: "attention_l0" (self-attention over all H*W
+ * tokens of the full-resolution blocks), "attention" (all 13), "forward" (whole U-Net forwards). */
+int ddpmir_profile_enable(ddpmir_ctx* ctx, int enable);
+int ddpmir_profile_read(ddpmir_ctx* ctx, const char* cls, double* ms, int64_t* launches, double* flops);
 const char* ddpmir_version(void);
 
 #ifdef __cplusplus

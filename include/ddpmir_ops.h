@@ -46,7 +46,7 @@ int ddpmir_op_time_embed(const float* t, int B, const float* w0, const float* b0
 /* uint8 quantisation (webp_inference.py:509) and one DDRM update (webp_inference.py:584-600) on NCHW images */
 int ddpmir_op_quantize_u8(const float* x, int64_t n, uint8_t* out);
 int ddpmir_op_ddrm_update(const float* x_theta, const uint8_t* dec_u8, const float* y, const float* noise,
-                          int64_t n_per_image, int B, float eta, float eta_b, float noise_coeff, int step_i, int steps,
+                          int64_t n_per_image, int B, double eta, double eta_b, double noise_coeff, int step_i, int steps,
                           float* out);
 int ddpmir_op_randn(int64_t n, uint64_t seed, uint64_t offset, float* out);
 

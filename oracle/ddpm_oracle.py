@@ -138,26 +138,54 @@ def adaptive_avg_pool(x, s):
     return out
 
 
+def _attn_chunk(q, k, v, scale):
+    sc = (q * scale) @ k.T
+    sc -= sc.max(axis=1, keepdims=True)
+    np.exp(sc, out=sc)
+    sc /= sc.sum(axis=1, keepdims=True)
+    return sc @ v
+
+
 def mha(tokens, in_w, in_b, out_w, out_b, heads):
-    """nn.MultiheadAttention(batch_first=True) self-attention, eval, no mask (webp_inference.py:317-321)."""
+    """nn.MultiheadAttention(batch_first=True) self-attention, eval, no mask (webp_inference.py:317-321).
+    Large token counts are processed in query chunks on a thread pool (numpy releases the GIL), so the
+    N x N scores are never held at once and all host cores are used when this is timed as the CPU baseline."""
     b, n, c = tokens.shape
     d = c // heads
     qkv = linear(tokens, in_w, in_b)
     q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
-    q = q.reshape(b, n, heads, d).transpose(0, 2, 1, 3)
-    k = k.reshape(b, n, heads, d).transpose(0, 2, 1, 3)
-    v = v.reshape(b, n, heads, d).transpose(0, 2, 1, 3)
+    q = np.ascontiguousarray(q.reshape(b, n, heads, d).transpose(0, 2, 1, 3))
+    k = np.ascontiguousarray(k.reshape(b, n, heads, d).transpose(0, 2, 1, 3))
+    v = np.ascontiguousarray(v.reshape(b, n, heads, d).transpose(0, 2, 1, 3))
     out = np.empty((b, heads, n, d), dtype=F32)
     scale = F32(1.0 / math.sqrt(d))
-    chunk = max(1, min(n, (1 << 24) // max(n, 1)))
-    for bi in range(b):
-        for hi in range(heads):
-            for s in range(0, n, chunk):
-                sc = (q[bi, hi, s:s + chunk] * scale) @ k[bi, hi].T
-                sc = sc - sc.max(axis=1, keepdims=True)
-                p = np.exp(sc)
-                p /= p.sum(axis=1, keepdims=True)
-                out[bi, hi, s:s + chunk] = p @ v[bi, hi]
+    chunk = max(1, min(n, (1 << 22) // max(n, 1)))
+    jobs = [(bi, hi, s) for bi in range(b) for hi in range(heads) for s in range(0, n, chunk)]
+
+    def run(job):
+        bi, hi, s = job
+        out[bi, hi, s:s + chunk] = _attn_chunk(q[bi, hi, s:s + chunk], k[bi, hi], v[bi, hi], scale)
+
+    if len(jobs) <= 2 or n < 4096:
+        for j in jobs:
+            run(j)
+    else:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            from threadpoolctl import threadpool_limits
+        except ImportError:
+            threadpool_limits = None
+        try:
+            nthreads = max(1, len(os.sched_getaffinity(0)))
+        except AttributeError:
+            nthreads = max(1, os.cpu_count() or 1)
+        with ThreadPoolExecutor(nthreads) as ex:
+            if threadpool_limits is not None:
+                with threadpool_limits(limits=1):
+                    list(ex.map(run, jobs))
+            else:
+                list(ex.map(run, jobs))
     out = out.transpose(0, 2, 1, 3).reshape(b, n, c)
     return linear(out, out_w, out_b)
 
