@@ -1,0 +1,74 @@
+"""Evaluation harness mirroring test_webp_restoration / test_avif_restoration (webp_inference.py:604-797,
+avif_inference.py:462-657): for every quality level compress -> pick steps -> restore -> score, and report the
+same JSON keys (`compressed_psnr` ... `restored_l2`).  PSNR and L2 are first-party formulas of the reference;
+SSIM/LPIPS/FID depend on third-party packages and stay optional in PyTorch.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+
+from . import codec, spec
+
+COMPRESS = {spec.ARCH_WEBP: codec.webp_compress, spec.ARCH_JPEG: codec.jpeg_compress, spec.ARCH_AVIF: codec.avif_compress}
+DEFAULT_QUALITIES = {spec.ARCH_WEBP: [0, 5, 10, 30, 50, 70, 90],      # webp_inference.py:604
+                     spec.ARCH_JPEG: [10, 20, 30, 50],                # svd.ipynb c1
+                     spec.ARCH_AVIF: [1, 10, 20, 30, 50, 70, 90]}     # avif_inference.py:462
+
+
+def steps_for_quality(arch: int, quality: int) -> int:
+    """init_t = clamp(int(100 - q), lo, hi)   (webp_inference.py:678-679, avif_inference.py:534-535)."""
+    k = spec.CONSTS[arch]
+    return max(k.steps_lo, min(k.steps_hi, int(100 - quality)))
+
+
+def psnr(a, b):
+    """-10 log10(mse + 1e-8) on clamp(x*0.5+0.5, 0, 1)   (webp_inference.py:691-697)."""
+    import torch
+    a01 = torch.clamp(a * 0.5 + 0.5, 0, 1)
+    b01 = torch.clamp(b * 0.5 + 0.5, 0, 1)
+    mse = torch.mean((a01 - b01) ** 2).item()
+    return -10.0 * math.log10(mse + 1e-8)
+
+
+def l2(a, b):
+    """torch.norm(a - b) / sqrt(numel)   (webp_inference.py:700-707)."""
+    import torch
+    a01 = torch.clamp(a * 0.5 + 0.5, 0, 1)
+    b01 = torch.clamp(b * 0.5 + 0.5, 0, 1)
+    return (torch.norm(a01 - b01) / math.sqrt(a01.numel())).item()
+
+
+def test_restoration(model, sampler, images, quality_levels=None, output_dir=None, seed=0, env=None):
+    """images: iterable of [B,3,H,W] tensors in [-1,1].  Returns {quality: averaged metrics} like the reference's
+    avg_results and writes metrics_summary.json when output_dir is given.  With a DistEnv the image list is
+    sharded across ranks and the sums are all-reduced."""
+    import torch
+    from . import dist as D
+    arch = model.ARCH
+    qs = quality_levels or DEFAULT_QUALITIES[arch]
+    batches = list(images)
+    if env is not None and env.world > 1:
+        lo, hi = D.shard_range(len(batches), env.rank, env.world)
+        batches = batches[lo:hi]
+    results = {}
+    for q in qs:
+        acc = [0.0, 0.0, 0.0, 0.0, 0.0]
+        for bi, x0 in enumerate(batches):
+            x0 = x0.to(model.device)
+            y = COMPRESS[arch](x0, q)
+            restored = sampler.sample(y, q, steps=steps_for_quality(arch, q), seed=seed + bi)
+            n = x0.shape[0]
+            acc[0] += psnr(y, x0) * n; acc[1] += psnr(restored, x0) * n
+            acc[2] += l2(y, x0) * n; acc[3] += l2(restored, x0) * n; acc[4] += n
+        if env is not None:
+            acc = D.reduce_metrics(acc, env, device=model.device)
+        n = max(acc[4], 1.0)
+        results[q] = {"compressed_psnr": acc[0] / n, "restored_psnr": acc[1] / n, "compressed_l2": acc[2] / n,
+                      "restored_l2": acc[3] / n, "psnr_gain": (acc[1] - acc[0]) / n, "count": int(acc[4])}
+    if output_dir and (env is None or env.rank == 0):
+        os.makedirs(output_dir, exist_ok=True)
+        with open(os.path.join(output_dir, "metrics_summary.json"), "w") as f:
+            json.dump({str(k): v for k, v in results.items()}, f, indent=2)
+    return results

@@ -1,0 +1,52 @@
+"""CPU: host-side logic of the package -- state-dict table, synthetic generators, codec module, sharding."""
+import numpy as np
+
+from ddpm_image_restoration_amd import codec, dist, spec, synth
+from oracle import ddpm_oracle as O
+
+
+def test_state_spec_counts():
+    # SURVEY.md / BASELINE.md: 114 398 409 parameters (WebP = JPEG), 158 284 137 (AVIF); 356 / 634 tensors
+    assert spec.param_count(spec.ARCH_WEBP) == 114398409
+    assert spec.param_count(spec.ARCH_JPEG) == 114398409
+    assert spec.param_count(spec.ARCH_AVIF) == 158284137
+    assert len(spec.state_spec(spec.ARCH_WEBP)) == 356
+    assert len(spec.state_spec(spec.ARCH_AVIF)) == 634
+    assert spec.gn_groups(3) == 3 and spec.gn_groups(64) == 8 and spec.gn_groups(7) == 7
+
+
+def test_synth_is_deterministic_and_named():
+    a = synth.synth_tensor("down2.conv1.weight", (128, 64, 3, 3), 0)
+    b = synth.synth_tensor("down2.conv1.weight", (128, 64, 3, 3), 0)
+    c = synth.synth_tensor("down3.conv1.weight", (128, 64, 3, 3), 0)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    d = synth.dct_matrix(8)
+    assert np.allclose(d @ d.T, np.eye(8), atol=1e-6)
+    img = synth.synth_images(2, 64)
+    assert img.shape == (2, 3, 64, 64) and img.min() >= -1 and img.max() <= 1
+
+
+def test_codec_module_matches_oracle_bit_exact(golden):
+    g = golden("codec")
+    for kind in ("webp", "jpeg", "avif"):
+        for q in (10, 50):
+            u8 = O.to_u8(g["in_32"])
+            assert np.array_equal(codec.roundtrip_u8(u8, q, kind), O.codec_u8(u8, q, kind))
+            assert np.array_equal(O.from_u8(codec.roundtrip_u8(u8, q, kind)), g[f"{kind}_q{q}_32"])
+
+
+def test_shard_range_partitions():
+    for n in (1, 7, 16, 128, 130):
+        for w in (1, 2, 3, 4, 8):
+            spans = [dist.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_harness_step_rule():
+    from ddpm_image_restoration_amd.harness import steps_for_quality
+    # webp_inference.py:678-679 clamp(100-q, 20, 80); avif_inference.py:534-535 clamp(100-q, 15, 75)
+    assert [steps_for_quality(spec.ARCH_WEBP, q) for q in (0, 10, 50, 90)] == [80, 80, 50, 20]
+    assert [steps_for_quality(spec.ARCH_AVIF, q) for q in (1, 30, 90)] == [75, 70, 15]
