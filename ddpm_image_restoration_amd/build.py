@@ -9,7 +9,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libddpmir.so")
-SOURCES = ["igemm.hip", "attention.hip", "pointwise.hip", "sampler_kernels.hip", "model.hip", "api.hip", "ops_api.hip"]
+SOURCES = ["igemm.hip", "attention.hip", "attention_bf16.hip", "pointwise.hip", "sampler_kernels.hip", "model.hip", "api.hip", "ops_api.hip"]
+# MFMA results feed VALU (softmax) directly: keep C/D in VGPRs instead of copying through AGPRs every tile
+VGPR_MFMA = {"attention_bf16.hip", "attention.hip"}
 NO_CONTRACT = {"sampler_kernels.hip"}   # bit-exact uint8 truncation path: no fma contraction
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -41,6 +43,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         extra = ["-ffp-contract=off"] if src in NO_CONTRACT else []
+        if src in VGPR_MFMA:
+            extra += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
         cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False

@@ -1,0 +1,364 @@
+// bf16 matrix-core self-attention for the restoration U-Net (reference: nn.MultiheadAttention,
+// webp_inference.py:295,317-321; 95 % of the FLOPs at 256^2 sit in the two full-resolution blocks with
+// N = 65 536 tokens and head_dim 16, where the kernel is bound by v_exp_f32 issue, not by MFMA).
+//
+// Two kernels:
+//  pack_qkv_bf16<D>   fp32 qkv [B][N][3C]  ->  bf16 operand images laid out exactly as the wave reads them:
+//      Qp [bh][Npad][DP]                       q * log2(e)/sqrt(d), d zero-padded to DP (multiple of 16)
+//      Kp [bh][tile][c][h][32 keys][8]         one 16-deep k chunk c, lane half h: lane l reads 16 B at l*16
+//      Vp [bh][tile][dt][s][h][rows][8]        V transposed AND key-permuted: slot j of lane half h at MFMA step s
+//                                              is key (j&3) + 8*(2s + (j>>2)) + 4h of the tile -- the key the
+//                                              S^T accumulator register 8s+j of that lane half holds.
+//      For D <= 16 the tile carries an extra row of ones (zeros for padding keys), so the PV MFMA also
+//      produces the softmax denominator in a spare accumulator row for free.
+//  flash_bf16<D,QS>   one wave = QS x 32 query rows, everything keyed by the query on the lane:
+//      S^T = K Q^T with the accumulator initialised to -m (running max) -> s - m comes out of the MFMA,
+//      p = v_exp_f32(s - m), packed to bf16 in place and used AS IS as the B operand of O^T += V^T P^T.
+//      The running max is only raised when a tile exceeds it by more than RESCALE_THR (deferred rescale;
+//      fp32 accumulators and bf16's 8-bit exponent make 2^THR-sized p harmless), so the per-tile VALU work
+//      is 16 v_exp + 8 v_max3 + 8 v_cvt_pk per 1024 scores.
+//  K/V stream through LDS in stages of several 32-key tiles (double buffered, register-staged: loads for
+//  stage i+1 are issued before the MFMAs of stage i, written to LDS after), laid out so every LDS read is
+//  a linear 1 KiB wave read (conflict-free).  Workgroups of one (batch, head) are placed on one XCD so the
+//  4 MiB of K/V they all re-read stay in that XCD's L2.
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace ddpmir {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+namespace {
+
+template <int D>
+struct AttnGeom {
+  static constexpr int DP = D < 16 ? 16 : D;               // k-padded head dim
+  static constexpr int KC = DP / 16;                       // 16-deep k chunks of QK^T
+  static constexpr bool ONES = D <= 16;                    // denominator via a ones row of V
+  static constexpr int DT = ONES ? 1 : D / 32;             // 32-row output tiles of O^T
+  static constexpr int RV = ONES ? D + 1 : 32;             // stored rows per (dt,s,h) slab of V^T
+  static constexpr int KT_BYTES = KC * 1024;
+  static constexpr int VT_BYTES = DT * 2 * 2 * RV * 16;
+  static constexpr int TILE_BYTES = KT_BYTES + VT_BYTES;
+  // default tiles per LDS stage: ~16 KiB per buffer
+  static constexpr int TS_DEFAULT = D <= 16 ? 8 : (D == 32 ? 4 : (D == 64 ? 2 : 1));
+};
+
+template <int D, int TS>
+struct StageGeom {
+  static constexpr int STAGE_BYTES = TS * AttnGeom<D>::TILE_BYTES;
+  static constexpr int CHUNKS = STAGE_BYTES / 16;
+  static constexpr int CPT = (CHUNKS + 255) / 256;         // 16-byte chunks per thread per stage
+};
+
+// key held by S^T accumulator register r of lane half h (C/D map of the 32x32 MFMA)
+__device__ __forceinline__ int acc_key(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------------ pack
+template <int D>
+__global__ __launch_bounds__(256) void pack_qkv_bf16(const float* __restrict__ qkv, __bf16* __restrict__ Qp,
+                                                     unsigned char* __restrict__ KVp, int N, int NT, int C,
+                                                     float qscale) {
+  using G = AttnGeom<D>;
+  __shared__ float sk[32][D + 1];
+  __shared__ float sv[32][D + 1];
+  const int tile = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int heads = gridDim.y;
+  const int bh = b * heads + head;
+  const int tid = threadIdx.x;
+  const float* base = qkv + (size_t)b * N * 3 * C + head * D;
+  // stage K and V of the 32 tokens; write Q directly
+  for (int i = tid; i < 32 * D; i += 256) {
+    int tok = i / D, c = i - tok * D;
+    int n = tile * 32 + tok;
+    float kq = 0.f, vq = 0.f, qq = 0.f;
+    if (n < N) {
+      const float* rp = base + (size_t)n * 3 * C + c;
+      qq = rp[0]; kq = rp[C]; vq = rp[2 * C];
+    }
+    sk[tok][c] = kq; sv[tok][c] = vq;
+    Qp[((size_t)bh * NT * 32 + n) * G::DP + c] = (__bf16)(qq * qscale);
+  }
+  if (G::DP > D)
+    for (int i = tid; i < 32 * (G::DP - D); i += 256) {
+      int tok = i / (G::DP - D), c = D + i % (G::DP - D);
+      Qp[((size_t)bh * NT * 32 + tile * 32 + tok) * G::DP + c] = (__bf16)0.f;
+    }
+  __syncthreads();
+  unsigned char* tbase = KVp + ((size_t)bh * NT + tile) * G::TILE_BYTES;
+  // K image: chunk (c, h, key) = comps 16c + 8h + j
+  for (int i = tid; i < G::KC * 64; i += 256) {
+    int c = i / 64, l = i - c * 64, h = l >> 5, key = l & 31;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int comp = 16 * c + 8 * h + j;
+      v[j] = (__bf16)(comp < D ? sk[key][comp] : 0.f);
+    }
+    *reinterpret_cast<bf16x8*>(tbase + c * 1024 + l * 16) = v;
+  }
+  // V^T image: slab (dt, s, h), row dd, slot j = key (j&3) + 8*(2s + (j>>2)) + 4h
+  unsigned char* vbase = tbase + G::KT_BYTES;
+  for (int i = tid; i < G::DT * 4 * G::RV; i += 256) {
+    int slab = i / G::RV, row = i - slab * G::RV;
+    int dt = slab >> 2, s = (slab >> 1) & 1, h = slab & 1;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int key = acc_key(8 * s + j, h);
+      float val;
+      if (G::ONES && row == D) val = (tile * 32 + key < N) ? 1.0f : 0.0f;
+      else val = sv[key][dt * 32 + row];
+      v[j] = (__bf16)val;
+    }
+    *reinterpret_cast<bf16x8*>(vbase + (size_t)slab * G::RV * 16 + row * 16) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ flash
+constexpr float RESCALE_THR = 20.0f;   // log2 units
+
+template <int D, int QS, int TS>
+__global__ __launch_bounds__(256) void flash_bf16(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
+                                                  float* __restrict__ out, int ldo, int N, int NT, int heads,
+                                                  int nqb, int npairs) {
+  using G = AttnGeom<D>;
+  using SG = StageGeom<D, TS>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 stage buffers
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // XCD-aware placement: workgroup ids are dealt round-robin over the 8 XCDs, so give every (batch, head)
+  // pair to one residue class -- all query blocks of a pair then share that XCD's L2 for K/V.
+  int wg = blockIdx.x, bh, qb;
+  if ((npairs & 7) == 0) {
+    int xcd = wg & 7, idx = wg >> 3;
+    bh = (idx / nqb) * 8 + xcd;
+    qb = idx - (idx / nqb) * nqb;
+  } else {
+    bh = wg / nqb;
+    qb = wg - bh * nqb;
+  }
+  const int b = bh / heads, head = bh - b * heads;
+  const int q0 = qb * (128 * QS) + wave * (32 * QS);
+
+  // Q fragments: lane (q = lr, half lh) holds comps 16c + 8lh + j
+  bf16x8 qf[QS][G::KC];
+#pragma unroll
+  for (int u = 0; u < QS; ++u) {
+    int qr = q0 + 32 * u + lr;
+    if (qr >= NT * 32) qr = NT * 32 - 1;
+    const __bf16* qp = Qp + ((size_t)bh * NT * 32 + qr) * G::DP + 8 * lh;
+#pragma unroll
+    for (int c = 0; c < G::KC; ++c) qf[u][c] = *reinterpret_cast<const bf16x8*>(qp + 16 * c);
+  }
+
+  f32x16 o[QS][G::DT], negm[QS];
+  float lsum[QS];
+#pragma unroll
+  for (int u = 0; u < QS; ++u) {
+    lsum[u] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[u][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[u][t][r] = 0.f;
+  }
+
+  const unsigned char* gkv = KVp + (size_t)bh * NT * G::TILE_BYTES;
+  const int nstages = (NT + TS - 1) / TS;
+  const size_t total_bytes = (size_t)NT * G::TILE_BYTES;
+  const int vrow = G::ONES ? (lr < D ? lr : D) : lr;     // row of the V^T slab this lane reads
+
+  float4 stg[SG::CPT];
+  auto gload = [&](int stage) {
+    const unsigned char* src = gkv + (size_t)stage * SG::STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < SG::CPT; ++i) {
+      size_t off = ((size_t)i * 256 + tid) * 16;
+      stg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((size_t)stage * SG::STAGE_BYTES + off < total_bytes && i * 256 + tid < SG::CHUNKS)
+        stg[i] = *reinterpret_cast<const float4*>(src + off);
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* dst = lds + buf * SG::STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < SG::CPT; ++i)
+      if (i * 256 + tid < SG::CHUNKS) *reinterpret_cast<float4*>(dst + ((size_t)i * 256 + tid) * 16) = stg[i];
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int st = 0; st < nstages; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstages) gload(st + 1);
+    const unsigned char* sb = lds + buf * SG::STAGE_BYTES;
+    const int tiles_here = min(TS, NT - st * TS);
+    for (int t = 0; t < tiles_here; ++t) {
+      const int kt = st * TS + t;
+      const unsigned char* tb = sb + t * G::TILE_BYTES;
+      bf16x8 kf[G::KC];
+#pragma unroll
+      for (int c = 0; c < G::KC; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(tb + c * 1024 + lane * 16);
+      bf16x8 vf[G::DT][2];
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          vf[dt][s] = *reinterpret_cast<const bf16x8*>(tb + G::KT_BYTES + ((dt * 2 + s) * 2 + lh) * (G::RV * 16) + vrow * 16);
+
+#pragma unroll
+      for (int u = 0; u < QS; ++u) {
+        f32x16 s = negm[u];
+#pragma unroll
+        for (int c = 0; c < G::KC; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[u][c], s, 0, 0, 0);
+        if (kt == NT - 1 && (N & 31) != 0) {   // padding keys of the last tile never win the max
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kt * 32 + acc_key(r, lh) >= N) s[r] = -INFINITY;
+        }
+        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, s[r]), s[r + 1]);
+        tmax = fmaxf(tmax, s[15]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const bool first = (kt == 0);
+        if (first || __any(tmax > RESCALE_THR)) {
+          // raise the running max of the rows that need it (every row on the first tile)
+          const float delta = first ? tmax : (tmax > RESCALE_THR ? tmax : 0.f);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[r] -= delta; negm[u][r] -= delta; }
+          if (!first) {
+            const float f = exp2f(-delta);
+            lsum[u] *= f;
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[u][dt][r] *= f;
+          }
+        }
+        bf16x8 pb[2];
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float p = __builtin_amdgcn_exp2f(s[r]);
+          if (!G::ONES) ps += p;
+          pb[r >> 3][r & 7] = (__bf16)p;
+        }
+        if (!G::ONES) lsum[u] += ps;
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) {
+          o[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], pb[0], o[u][dt], 0, 0, 0);
+          o[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][1], pb[1], o[u][dt], 0, 0, 0);
+        }
+      }
+    }
+    if (st + 1 < nstages) {
+      lstore(buf ^ 1);     // buffer buf^1 was last read in stage st-1, fenced by that stage's barrier
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: O = O^T / l ; lane (q, half h) holds dd = (r&3) + 8(r>>2) + 4h + 32dt
+#pragma unroll
+  for (int u = 0; u < QS; ++u) {
+    float l;
+    if (G::ONES) l = __shfl(o[u][0][(D / 8) * 4], lr);   // row D of O^T: register (D/8)*4 of lane half 0
+    else l = lsum[u] + __shfl_xor(lsum[u], 32);
+    const float inv = 1.0f / l;
+    const int qr = q0 + 32 * u + lr;
+    if (qr < N) {
+      float* op = out + ((size_t)b * N + qr) * ldo + head * D;
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = dt * 32 + 8 * g + 4 * lh;
+          if (dd < D)
+            *reinterpret_cast<float4*>(op + dd) = make_float4(o[u][dt][4 * g] * inv, o[u][dt][4 * g + 1] * inv,
+                                                              o[u][dt][4 * g + 2] * inv, o[u][dt][4 * g + 3] * inv);
+        }
+    }
+  }
+}
+
+template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT>
+void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* ws, hipStream_t s) {
+  using G = AttnGeom<D>;
+  using SG = StageGeom<D, TS>;
+  const int NT = (N + 31) / 32;
+  const int BH = B * heads;
+  __bf16* Qp = static_cast<__bf16*>(ws);
+  size_t q_bytes = ((size_t)BH * NT * 32 * G::DP * 2 + 255) & ~size_t(255);
+  unsigned char* KVp = static_cast<unsigned char*>(ws) + q_bytes;
+  const float qscale = 1.44269504088896340736f / sqrtf((float)D);
+  hipLaunchKernelGGL(pack_qkv_bf16<D>, dim3(NT, heads, B), dim3(256), 0, s, qkv, Qp, KVp, N, NT, C, qscale);
+  const int nqb = (N + 128 * QS - 1) / (128 * QS);
+  static bool attr_set = false;
+  if (!attr_set) {
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16<D, QS, TS>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SG::STAGE_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((flash_bf16<D, QS, TS>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES, s, Qp, KVp, out, ldo,
+                     N, NT, heads, nqb, BH);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+template <int D>
+size_t ws_bytes_for(int B, int N, int heads) {
+  using G = AttnGeom<D>;
+  const size_t NT = (N + 31) / 32, BH = (size_t)B * heads;
+  return ((BH * NT * 32 * G::DP * 2 + 255) & ~size_t(255)) + BH * NT * G::TILE_BYTES + 256;
+}
+
+}  // namespace
+
+bool attention_bf16_supported(int N, int C, int heads) {
+  const int D = C / heads;
+  return (D == 8 || D == 16 || D == 32 || D == 64 || D == 128) && N >= 64;
+}
+
+size_t attention_bf16_workspace(int B, int N, int C, int heads) {
+  switch (C / heads) {
+    case 8: return ws_bytes_for<8>(B, N, heads);
+    case 16: return ws_bytes_for<16>(B, N, heads);
+    case 32: return ws_bytes_for<32>(B, N, heads);
+    case 64: return ws_bytes_for<64>(B, N, heads);
+    case 128: return ws_bytes_for<128>(B, N, heads);
+    default: return 0;
+  }
+}
+
+void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* workspace,
+                           hipStream_t s) {
+  static const int var = [] { const char* e = getenv("DDPMIR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // tuning knob
+  if (C / heads == 16 && var != 0) {
+    switch (var) {
+      case 1: run_flash<16, 1, 16>(qkv, out, ldo, B, N, C, heads, workspace, s); return;
+      case 2: run_flash<16, 1, 8>(qkv, out, ldo, B, N, C, heads, workspace, s); return;
+      case 3: run_flash<16, 1, 4>(qkv, out, ldo, B, N, C, heads, workspace, s); return;
+      case 4: run_flash<16, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s); return;
+      case 5: run_flash<16, 2, 8>(qkv, out, ldo, B, N, C, heads, workspace, s); return;
+      case 6: run_flash<16, 2, 4>(qkv, out, ldo, B, N, C, heads, workspace, s); return;
+      default: break;
+    }
+  }
+  switch (C / heads) {
+    case 8: run_flash<8, 1>(qkv, out, ldo, B, N, C, heads, workspace, s); break;
+    case 16: run_flash<16, 1>(qkv, out, ldo, B, N, C, heads, workspace, s); break;
+    case 32: run_flash<32, 1>(qkv, out, ldo, B, N, C, heads, workspace, s); break;
+    case 64: run_flash<64, 1>(qkv, out, ldo, B, N, C, heads, workspace, s); break;
+    case 128: run_flash<128, 1>(qkv, out, ldo, B, N, C, heads, workspace, s); break;
+    default: throw std::runtime_error("attention_bf16: unsupported head dim");
+  }
+}
+
+}  // namespace ddpmir

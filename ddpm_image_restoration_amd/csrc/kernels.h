@@ -37,6 +37,13 @@ void launch_igemm(const IGemm& p, hipStream_t stream);
 // out is [B][N][ldo] (first C columns).  Reference: nn.MultiheadAttention core, webp_inference.py:319.
 void launch_attention(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, hipStream_t stream);
 
+// bf16 matrix-core variant (attention_bf16.hip): qkv/out stay fp32 in HBM, Q/K/V are repacked to bf16 operand
+// images in `workspace` (attention_bf16_workspace() bytes), softmax statistics and accumulators are fp32.
+bool attention_bf16_supported(int N, int C, int heads);
+size_t attention_bf16_workspace(int B, int N, int C, int heads);
+void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* workspace,
+                           hipStream_t stream);
+
 // ------------------------------------------------------------------------------------------------ pointwise
 // GroupNorm statistics -> per-(b,c) scale/shift so that norm(x) = x*scale + shift (eps 1e-5, biased var).
 // `partial` is scratch of >= B*G*gn_splits(...)*2 doubles.

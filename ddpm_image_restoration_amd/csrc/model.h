@@ -110,6 +110,7 @@ class Context {
     float* u[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // outputs of up blocks, index = level
     float *hA = nullptr, *hB = nullptr, *qkv = nullptr, *att = nullptr, *xd = nullptr, *hid = nullptr, *S = nullptr;
     float *xt = nullptr, *avg = nullptr, *col = nullptr, *edge = nullptr, *pool = nullptr, *pg1 = nullptr, *pg2 = nullptr;
+    unsigned char* attn_ws = nullptr;
     double* gn_partial = nullptr;
     float *sc1 = nullptr, *sh1 = nullptr, *sc2 = nullptr, *sh2 = nullptr;
     float *hidden = nullptr, *temb = nullptr, *tproj = nullptr;

@@ -38,7 +38,7 @@ ArchConsts consts_for(int arch) {
 }  // namespace
 
 Context::Context(const ddpmir_config& c) : cfg(c), k(consts_for(c.arch)) {
-  if (cfg.dtype != DDPMIR_F32) throw std::runtime_error("dtype: only DDPMIR_F32 is built in this version");
+  if (cfg.dtype != DDPMIR_F32 && cfg.dtype != DDPMIR_BF16) throw std::runtime_error("dtype must be DDPMIR_F32 or DDPMIR_BF16");
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
   DDPMIR_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   DDPMIR_HIP_CHECK(hipEventCreate(&ev0_));
@@ -237,6 +237,13 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
     p.xt = a.take<float>(mc); p.avg = a.take<float>(mc); p.col = a.take<float>(mc); p.edge = a.take<float>(mc);
     p.pool = a.take<float>((size_t)B * 64 * 1024); p.pg1 = a.take<float>((size_t)B * 64 * 256);
     p.pg2 = a.take<float>((size_t)B * 64 * 1024);
+  }
+  if (cfg.dtype == DDPMIR_BF16) {
+    size_t ws = 0;
+    for (auto& d : kBlocks)
+      if (d.level >= cfg.attn_min_level && attention_bf16_supported((int)hw(d.level), d.cout, k.heads))
+        ws = std::max(ws, attention_bf16_workspace(B, (int)hw(d.level), d.cout, k.heads));
+    p.attn_ws = a.take<unsigned char>(ws + 256);
   }
   int max_splits = gn_splits(H * W, 64);
   p.gn_partial = a.take<double>((size_t)B * 8 * max_splits * 2 + 64);
@@ -442,7 +449,10 @@ void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int 
     // algorithmic FLOPs of QK^T + PV: 4 * N^2 * C per image
     const double nn = (double)H * W;
     prof_begin(bw.level == 0 ? PROF_ATTN_L0 : PROF_ATTN, 4.0 * nn * nn * C * B, s);
-    launch_attention(p.qkv, p.att, C, B, H * W, C, k.heads, s);
+    if (cfg.dtype == DDPMIR_BF16 && attention_bf16_supported(H * W, C, k.heads))
+      launch_attention_bf16(p.qkv, p.att, C, B, H * W, C, k.heads, p.attn_ws, s);
+    else
+      launch_attention(p.qkv, p.att, C, B, H * W, C, k.heads, s);
     prof_end(s);
     IGemm o = g; o.A = p.att; o.lda = C; o.res = p.hB; o.ldres = C; o.out = p.hB; o.ldo = C;
     conv(bw.out_proj, o, s);

@@ -119,6 +119,46 @@ int ddpmir_op_attention(const float* qkv, int B, int N, int C, int heads, float*
   });
 }
 
+int ddpmir_op_attention_bf16(const float* qkv, int B, int N, int C, int heads, float* out) {
+  return guarded([&] {
+    if (!attention_bf16_supported(N, C, heads)) throw std::runtime_error("attention_bf16: unsupported shape");
+    Dev d;
+    float* q = d.up(qkv, (size_t)B * N * 3 * C);
+    float* o = d.alloc<float>((size_t)B * N * C);
+    unsigned char* ws = d.alloc<unsigned char>(attention_bf16_workspace(B, N, C, heads) + 256);
+    launch_attention_bf16(q, o, C, B, N, C, heads, ws, nullptr);
+    d.down(out, o, (size_t)B * N * C);
+  });
+}
+
+int ddpmir_op_attention_time(int B, int N, int C, int heads, int mode, int iters, float* ms_per_call) {
+  return guarded([&] {
+    Dev d;
+    const size_t n = (size_t)B * N * 3 * C;
+    float* q = d.alloc<float>(n + 4);
+    launch_randn(q, (int64_t)n, 1234, 0, nullptr);
+    float* o = d.alloc<float>((size_t)B * N * C);
+    unsigned char* ws = mode ? d.alloc<unsigned char>(attention_bf16_workspace(B, N, C, heads) + 256) : nullptr;
+    hipEvent_t a, b;
+    DDPMIR_HIP_CHECK(hipEventCreate(&a));
+    DDPMIR_HIP_CHECK(hipEventCreate(&b));
+    auto run = [&] {
+      if (mode) launch_attention_bf16(q, o, C, B, N, C, heads, ws, nullptr);
+      else launch_attention(q, o, C, B, N, C, heads, nullptr);
+    };
+    run();
+    DDPMIR_HIP_CHECK(hipDeviceSynchronize());
+    DDPMIR_HIP_CHECK(hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) run();
+    DDPMIR_HIP_CHECK(hipEventRecord(b, nullptr));
+    DDPMIR_HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0.f;
+    DDPMIR_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    *ms_per_call = ms / iters;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  });
+}
+
 int ddpmir_op_block_transform(const float* x, int B, int H, int W, int C, int bs, const float* mats, int per_channel,
                               float mix_in, float mix_t, float* out) {
   return guarded([&] {

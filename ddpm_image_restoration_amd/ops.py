@@ -15,6 +15,8 @@ _sigs = {
                                  C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P]),
     "ddpmir_op_gn_scale_shift": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "ddpmir_op_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ddpmir_op_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ddpmir_op_attention_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ddpmir_op_block_transform": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float,
                                             C.c_float, _P]),
     "ddpmir_op_maxpool2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
@@ -88,13 +90,21 @@ def gn_scale_shift(x, groups, gamma, beta):
     return sc, sh
 
 
-def attention(qkv, heads):
+def attention(qkv, heads, bf16=False):
     lib = _lib_ops()
     qkv = _f(qkv)
     b, n, c3 = qkv.shape
     out = np.empty((b, n, c3 // 3), np.float32)
-    _chk(lib, lib.ddpmir_op_attention(_p(qkv), b, n, c3 // 3, heads, _p(out)), "op_attention")
+    fn = lib.ddpmir_op_attention_bf16 if bf16 else lib.ddpmir_op_attention
+    _chk(lib, fn(_p(qkv), b, n, c3 // 3, heads, _p(out)), "op_attention")
     return out
+
+
+def attention_time(b, n, c, heads, mode, iters=3):
+    lib = _lib_ops()
+    ms = C.c_float(0)
+    _chk(lib, lib.ddpmir_op_attention_time(b, n, c, heads, mode, iters, C.byref(ms)), "op_attention_time")
+    return ms.value
 
 
 def block_transform(x, mats, mix_in=0.0, mix_t=1.0):

@@ -29,6 +29,10 @@ int ddpmir_op_gn_scale_shift(const float* x, int B, int HW, int C, int G, const 
 
 /* attention core on qkv [B,N,3C] -> out [B,N,C] (webp_inference.py:319) */
 int ddpmir_op_attention(const float* qkv, int B, int N, int C, int heads, float* out);
+/* same through the bf16 matrix-core kernel (fp32 in/out, bf16 operands, fp32 accumulation) */
+int ddpmir_op_attention_bf16(const float* qkv, int B, int N, int C, int heads, float* out);
+/* device-resident timing of the attention kernels on random data: mode 0 = fp32, 1 = bf16; average ms per call */
+int ddpmir_op_attention_time(int B, int N, int C, int heads, int mode, int iters, float* ms_per_call);
 
 /* blockwise T X T^T (DCTLayer webp_inference.py:161-192 / AVIFAdaptiveTransform avif_inference.py:140-177) */
 int ddpmir_op_block_transform(const float* x, int B, int H, int W, int C, int bs, const float* mats, int per_channel,

@@ -55,6 +55,20 @@ def test_forward_golden_64_and_nonsquare(name, arch, golden, models):
 
 
 @pytest.mark.parametrize("name,arch", ARCHS)
+def test_forward_bf16_mode(name, arch, golden, models):
+    """dtype='bf16': matrix-core contractions on bf16 operands, fp32 accumulation / statistics / storage.
+    Tolerance per SURVEY.md H2: teacher-forced x_theta within 2e-2 of the fp32 reference."""
+    g = golden(name)
+    m = models(arch, dtype="bf16")
+    y = m(tt(g["fwd32_x"]), tt(g["fwd32_t"]), tt(g["fwd32_cl"])).cpu().numpy()
+    err = np.abs(y - g["fwd32_y"])
+    assert err.max() < 2e-2 and err.mean() < 2e-3, (err.max(), err.mean())
+    y = m(tt(g["fwd64_x"]), tt(g["fwd64_t"]), tt(g["fwd64_t"])).cpu().numpy()
+    err = np.abs(y - g["fwd64_y"])
+    assert err.max() < 2e-2 and err.mean() < 2e-3, (err.max(), err.mean())
+
+
+@pytest.mark.parametrize("name,arch", ARCHS)
 def test_forward_graph_replay_matches_eager(name, arch, golden, models):
     g = golden(name)
     y0 = models(arch)(tt(g["fwd32_x"]), tt(g["fwd32_t"]), tt(g["fwd32_cl"])).cpu().numpy()

@@ -123,6 +123,51 @@ def test_attention(ops, N, C, heads):
     close(got, ref, 2e-5)
 
 
+@pytest.mark.parametrize("N,C,heads", [(256, 64, 4), (1024, 64, 4), (4096, 64, 4), (256, 128, 4), (1024, 128, 4),
+                                       (64, 256, 4), (576, 256, 4), (64, 512, 4), (256, 512, 4), (96, 64, 8),
+                                       (200, 128, 8), (1000, 64, 4), (2048, 64, 8)])
+def test_attention_bf16(ops, N, C, heads):
+    """bf16 matrix-core kernel: operands rounded to bf16, fp32 softmax statistics and accumulation."""
+    B = 2
+    qkv = rnd(B, N, 3 * C, seed=40, scale=1.5)
+    d = C // heads
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    sp = lambda z: z.reshape(B, N, heads, d).transpose(0, 2, 1, 3).astype(np.float64)
+    s = (sp(q) / np.sqrt(d)) @ sp(k).transpose(0, 1, 3, 2)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ sp(v)).transpose(0, 2, 1, 3).reshape(B, N, C).astype(np.float32)
+    got = ops.attention(qkv, heads, bf16=True)
+    err = np.abs(got - ref).max()
+    assert err < 8e-2, err            # bf16 operands: 2^-8 relative on q, k, v, p
+    assert np.abs(got - ref).mean() < 4e-3
+
+
+def test_attention_bf16_spiky_and_shifted(ops):
+    """forces the deferred-rescale branch mid-sequence and a large negative common offset (first-tile init)."""
+    B, N, C, heads = 1, 2048, 64, 4
+    qkv = rnd(B, N, 3 * C, seed=41)
+    qkv[0, 7, :16] *= 25
+    qkv[0, 1500, C:C + 16] = qkv[0, 7, :16] * 2      # score ~ +2*|q|^2/4 far above everything before it
+    qkv[0, :, 16:32] = 6.0                           # head 1: q constant
+    qkv[0, :, C + 16:C + 32] = -6.0                  # head 1: k constant negative -> all scores ~ -144
+    d = C // heads
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    bf = lambda z: (z.astype(np.float32).view(np.uint32) + 0x7FFF + ((z.astype(np.float32).view(np.uint32) >> 16) & 1) & 0xFFFF0000).view(np.float32)
+    sp = lambda z: z.reshape(B, N, heads, d).transpose(0, 2, 1, 3).astype(np.float64)
+    s = (sp(q) / np.sqrt(d)) @ sp(k).transpose(0, 1, 3, 2)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ sp(v)).transpose(0, 2, 1, 3).reshape(B, N, C).astype(np.float32)
+    got = ops.attention(qkv, heads, bf16=True)
+    assert np.isfinite(got).all()
+    # row 7 of head 0 is a one-hot on key 1500 (bf16 rounding of v only)
+    assert np.abs(got[0, 7, :16] - ref[0, 7, :16]).max() < 3e-2
+    assert np.abs(got - ref).mean() < 6e-3
+
+
 def test_attention_spiky_softmax(ops):
     """a query/key pair with a huge score forces the online-softmax rescale path mid-sequence."""
     B, N, C, heads = 1, 512, 64, 4
