@@ -181,6 +181,194 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemm p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ bf16 variant
+// Same tiling and fusions, operands rounded to bf16 on the way into LDS, v_mfma_f32_32x32x16_bf16 (fp32
+// accumulate).  K chunk = 64 channels; LDS rows are 64 bf16 + 8 pad (144 B, conflict-free b128 reads); a lane
+// reads 16 B = 8 consecutive k.  Weights come from the bf16 copy of the packed blob.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+constexpr int BK16 = 64;
+constexpr int LROW16 = BK16 * 2 + 16;   // bytes
+
+template <int NT>
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[BM * LROW16];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[NT * 32 * LROW16];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int q = tid & 7;        // 8-channel group inside the 64-channel chunk
+  const int r0 = tid >> 3;
+  const int M = p.B * p.H * p.W;
+  const int HW = p.H * p.W;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * (NT * 32);
+  const int nck = (p.Cin + BK16 - 1) / BK16;
+  const int nit = p.taps * nck;
+  const bool affine = p.scale != nullptr;
+  const __bf16* Wb = reinterpret_cast<const __bf16*>(p.Wt16);
+
+  int a_b[4], a_y[4], a_x[4];
+  bool a_ok[4];
+  size_t a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + r0 + 32 * i;
+    bool ok = m < M;
+    int mm = ok ? m : 0;
+    int b = mm / HW, rem = mm - b * HW;
+    int y = rem / p.W, x = rem - y * p.W;
+    if (ok && p.pro_mask != MASK_NONE) {
+      bool lowp = is_low_freq(y, x, p.H, p.W, p.bs, p.low);
+      ok = (p.pro_mask == MASK_LOW) ? lowp : !lowp;
+    }
+    a_b[i] = b; a_y[i] = y; a_x[i] = x; a_ok[i] = ok;
+    a_off[i] = (size_t)mm * p.lda;
+  }
+
+  float4 a_lo[4], a_hi[4];
+  bool a_val[4], c_lo = false, c_hi = false;
+  int cur_c = 0;
+  bf16x8 b_reg[NT];
+
+  auto gload = [&](int it) {
+    int tap = it / nck;
+    int c = (it - tap * nck) * BK16 + 8 * q;
+    cur_c = c;
+    int dy = 0, dx = 0;
+    if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+    c_lo = c < p.Cin; c_hi = c + 4 < p.Cin;           // Cin is a multiple of 4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bool ok = a_ok[i] && c_lo && (unsigned)(a_y[i] + dy) < (unsigned)p.H && (unsigned)(a_x[i] + dx) < (unsigned)p.W;
+      a_val[i] = ok;
+      a_lo[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a_hi[i] = a_lo[i];
+      if (ok) {
+        const float* src = p.A + a_off[i] + (ptrdiff_t)(dy * p.W + dx) * p.lda + c;
+        a_lo[i] = *reinterpret_cast<const float4*>(src);
+        if (c_hi) a_hi[i] = *reinterpret_cast<const float4*>(src + 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      int n = n0 + r0 + 32 * i;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b_reg[i][j] = (__bf16)0.f;
+      if (n < p.Cout && c_lo) {
+        const __bf16* src = Wb + ((size_t)tap * p.Cout + n) * p.Cin + c;
+        if (c_hi) b_reg[i] = *reinterpret_cast<const bf16x8*>(src);
+        else {
+          typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+          bf16x4 t4 = *reinterpret_cast<const bf16x4*>(src);
+          b_reg[i][0] = t4[0]; b_reg[i][1] = t4[1]; b_reg[i][2] = t4[2]; b_reg[i][3] = t4[3];
+        }
+      }
+    }
+  };
+
+  auto xform = [&](float v, float sc, float sh) {
+    if (affine) v = fmaf(v, sc, sh);
+    if (p.pro_act != ACT_NONE) v = act_apply(v, p.pro_act);
+    return v;
+  };
+
+  auto lds_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x8 o;
+      if (a_val[i]) {
+        float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, h0 = make_float4(0.f, 0.f, 0.f, 0.f), h1 = h0;
+        if (affine) {
+          const float* sp = p.scale + (size_t)a_b[i] * p.Cin + cur_c;
+          const float* hp = p.shift + (size_t)a_b[i] * p.Cin + cur_c;
+          s0 = *reinterpret_cast<const float4*>(sp); h0 = *reinterpret_cast<const float4*>(hp);
+          if (c_hi) { s1 = *reinterpret_cast<const float4*>(sp + 4); h1 = *reinterpret_cast<const float4*>(hp + 4); }
+        }
+        o[0] = (__bf16)xform(a_lo[i].x, s0.x, h0.x); o[1] = (__bf16)xform(a_lo[i].y, s0.y, h0.y);
+        o[2] = (__bf16)xform(a_lo[i].z, s0.z, h0.z); o[3] = (__bf16)xform(a_lo[i].w, s0.w, h0.w);
+        if (c_hi) {
+          o[4] = (__bf16)xform(a_hi[i].x, s1.x, h1.x); o[5] = (__bf16)xform(a_hi[i].y, s1.y, h1.y);
+          o[6] = (__bf16)xform(a_hi[i].z, s1.z, h1.z); o[7] = (__bf16)xform(a_hi[i].w, s1.w, h1.w);
+        } else {
+          o[4] = o[5] = o[6] = o[7] = (__bf16)0.f;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(&As[(r0 + 32 * i) * LROW16 + 16 * q]) = o;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) *reinterpret_cast<bf16x8*>(&Bs[(r0 + 32 * i) * LROW16 + 16 * q]) = b_reg[i];
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int lr = lane & 31;
+  const int lh = lane >> 5;
+  const unsigned char* a_rd = &As[(wave * 32 + lr) * LROW16 + 16 * lh];
+  const unsigned char* b_rd = &Bs[lr * LROW16 + 16 * lh];
+
+  gload(0);
+  for (int it = 0; it < nit; ++it) {
+    lds_store();
+    __syncthreads();
+    if (it + 1 < nit) gload(it + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK16 / 16; ++ks) {
+      bf16x8 a8 = *reinterpret_cast<const bf16x8*>(a_rd + 32 * ks);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        bf16x8 b8 = *reinterpret_cast<const bf16x8*>(b_rd + nt * 32 * LROW16 + 32 * ks);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE || p.store == STORE_NCHW;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    int m = m0 + row;
+    if (m >= M) continue;
+    int b = 0, y = 0, x = 0;
+    if (need_pos) {
+      b = m / HW;
+      int rem = m - b * HW;
+      y = rem / p.W;
+      x = rem - y * p.W;
+    }
+    bool keep = true;
+    if (p.epi_mask != MASK_NONE) {
+      bool lowp = is_low_freq(y, x, p.H, p.W, p.bs, p.low);
+      keep = (p.epi_mask == MASK_LOW) ? lowp : !lowp;
+    }
+    float rs = p.rowscale ? p.rowscale[b] : 1.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      int n = n0 + nt * 32 + lr;
+      if (n >= p.Cout) continue;
+      float v = acc[nt][r];
+      if (p.bias) v += p.bias[n];
+      if (p.tb) v += p.tb[(size_t)b * p.ldtb + n];
+      v = act_apply(v, p.epi_act);
+      if (p.mul) v *= p.mul[(size_t)m * p.ldmul + n];
+      if (p.rowscale) v *= rs;
+      if (!keep) v = 0.f;
+      if (p.res) v += p.res[(size_t)m * p.ldres + n];
+      if (p.store == STORE_NHWC) p.out[(size_t)m * p.ldo + n] = v;
+      else p.out[(((size_t)b * p.Cout + n) * p.H + y) * p.W + x] = v;
+    }
+  }
+}
+
 }  // namespace
 
 void launch_igemm(const IGemm& p, hipStream_t stream) {
@@ -190,6 +378,13 @@ void launch_igemm(const IGemm& p, hipStream_t stream) {
   const int64_t M = (int64_t)p.B * p.H * p.W;
   if (M <= 0 || p.Cout <= 0) return;
   dim3 block(256);
+  if (p.Wt16) {
+    if (p.Cout <= 32) hipLaunchKernelGGL(igemm_bf16_kernel<1>, dim3((unsigned)cdiv64(M, BM), 1), block, 0, stream, p);
+    else if (p.Cout <= 64) hipLaunchKernelGGL(igemm_bf16_kernel<2>, dim3((unsigned)cdiv64(M, BM), 1), block, 0, stream, p);
+    else hipLaunchKernelGGL(igemm_bf16_kernel<4>, dim3((unsigned)cdiv64(M, BM), (unsigned)cdiv(p.Cout, 128)), block, 0, stream, p);
+    DDPMIR_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (p.Cout <= 32) {
     dim3 grid((unsigned)cdiv64(M, BM), 1);
     hipLaunchKernelGGL(igemm_kernel<1>, grid, block, 0, stream, p);

@@ -15,6 +15,7 @@ struct IGemm {
   int B = 1, H = 1, W = 1, Cin = 0;
   // weights, packed [taps][Cout][Cin]
   const float* Wt = nullptr; int Cout = 0; int taps = 1;
+  const void* Wt16 = nullptr;                 // same layout in bf16: selects the bf16 matrix-core kernel
   const float* bias = nullptr;                // [Cout] or null
   // prologue: v = A*scale[b][c] + shift[b][c]; act; static frequency mask on the pixel position
   const float* scale = nullptr; const float* shift = nullptr;   // [B][Cin] or null

@@ -31,6 +31,7 @@ struct Arena {
 
 struct ConvW {          // packed [taps][Cout][CinP] + bias
   float* w = nullptr; float* b = nullptr;
+  void* w16 = nullptr;  // bf16 copy (DDPMIR_BF16 contexts)
   int cout = 0, cin = 0, cinp = 0, taps = 1;
 };
 

@@ -85,6 +85,7 @@ void Context::put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name
   const size_t n = (size_t)cw.taps * cout * cw.cinp;
   cw.w = a.take<float>(n);
   cw.b = a.take<float>(cout);
+  cw.w16 = cfg.dtype == DDPMIR_BF16 ? a.take<unsigned short>(n) : nullptr;
   n_params_ += (int64_t)cout * cin * cw.taps + cout;
   if (!upload) return;
   auto iw = host_.find(name + ".weight");
@@ -100,6 +101,15 @@ void Context::put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name
     for (int c = 0; c < cin; ++c)
       for (int t = 0; t < cw.taps; ++t) packed[((size_t)t * cout + o) * cw.cinp + c] = src[((size_t)o * cin + c) * cw.taps + t];
   DDPMIR_HIP_CHECK(hipMemcpy(cw.w, packed.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  if (cw.w16) {   // round-to-nearest-even bf16 copy for the matrix cores
+    std::vector<unsigned short> p16(n);
+    for (size_t i = 0; i < n; ++i) {
+      unsigned int u;
+      std::memcpy(&u, &packed[i], 4);
+      p16[i] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    }
+    DDPMIR_HIP_CHECK(hipMemcpy(cw.w16, p16.data(), n * 2, hipMemcpyHostToDevice));
+  }
   DDPMIR_HIP_CHECK(hipMemcpy(cw.b, ib->second.data.data(), cout * sizeof(float), hipMemcpyHostToDevice));
 }
 
@@ -358,7 +368,7 @@ void Context::profile_read(const std::string& cls, double* ms, int64_t* launches
 
 // ------------------------------------------------------------------------------------------------ forward
 void Context::conv(const ConvW& cw, IGemm p, hipStream_t s) {
-  p.Wt = cw.w; p.bias = cw.b; p.Cout = cw.cout; p.Cin = cw.cinp; p.taps = cw.taps;
+  p.Wt = cw.w; p.Wt16 = cw.w16; p.bias = cw.b; p.Cout = cw.cout; p.Cin = cw.cinp; p.taps = cw.taps;
   launch_igemm(p, s);
 }
 

@@ -1,4 +1,5 @@
 // Host-buffer single-operator entry points (include/ddpmir_ops.h) used by the per-operator parity tests.
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -11,6 +12,7 @@ using namespace ddpmir;
 
 namespace {
 thread_local std::string g_err;
+thread_local int g_bf16 = 0;
 
 struct Dev {
   std::vector<void*> ptrs;
@@ -52,6 +54,7 @@ int guarded(F&& f) {
 extern "C" {
 
 const char* ddpmir_ops_last_error(void) { return g_err.c_str(); }
+void ddpmir_op_set_bf16(int enable) { g_bf16 = enable; }
 
 int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
                    int ksize, const float* scale, const float* shift, int pro_act, int pro_mask, int bs, int low,
@@ -71,6 +74,16 @@ int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_
     IGemm p;
     p.A = d.up(xp.data(), xp.size()); p.lda = cinp; p.B = B; p.H = H; p.W = W; p.Cin = cinp;
     p.Wt = d.up(wp.data(), wp.size()); p.Cout = Cout; p.taps = taps; p.bias = d.up(bias, Cout);
+    std::vector<unsigned short> w16;
+    if (g_bf16) {
+      w16.resize(wp.size());
+      for (size_t i = 0; i < wp.size(); ++i) {
+        unsigned int u;
+        memcpy(&u, &wp[i], 4);
+        w16[i] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+      }
+      p.Wt16 = d.up(w16.data(), w16.size());
+    }
     if (scale) {
       sp.assign((size_t)B * cinp, 0.f); hp.assign((size_t)B * cinp, 0.f);
       for (int b = 0; b < B; ++b)

@@ -13,6 +13,7 @@ _sigs = {
     "ddpmir_ops_last_error": (C.c_char_p, []),
     "ddpmir_op_conv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int,
                                  C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P]),
+    "ddpmir_op_set_bf16": (None, [C.c_int]),
     "ddpmir_op_gn_scale_shift": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "ddpmir_op_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ddpmir_op_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
@@ -62,8 +63,9 @@ MASK = {None: 0, "none": 0, "low": 1, "high": 2}
 
 
 def conv(x, w, bias=None, scale=None, shift=None, pro_act=None, pro_mask=None, bs=4, low=3, tb=None, epi_act=None,
-         mul=None, rowscale=None, epi_mask=None, res=None, nchw_out=False):
+         mul=None, rowscale=None, epi_mask=None, res=None, nchw_out=False, bf16=False):
     lib = _lib_ops()
+    lib.ddpmir_op_set_bf16(int(bf16))
     x, w = _f(x), _f(w)
     if w.ndim == 2:
         w = w[:, :, None, None]

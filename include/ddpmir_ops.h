@@ -22,6 +22,8 @@ int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_
                    int ksize, const float* scale, const float* shift, int pro_act, int pro_mask, int bs, int low,
                    const float* tb, int epi_act, const float* mul, const float* rowscale, int epi_mask,
                    const float* res, int nchw_out, float* out);
+/* select the bf16 matrix-core variant for subsequent ddpmir_op_conv calls of this thread (0 = fp32) */
+void ddpmir_op_set_bf16(int enable);
 
 /* nn.GroupNorm statistics folded to per-(b,c) scale/shift (webp_inference.py:281); x [B,HW,C]. */
 int ddpmir_op_gn_scale_shift(const float* x, int B, int HW, int C, int G, const float* gamma, const float* beta,

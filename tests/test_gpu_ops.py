@@ -45,6 +45,36 @@ def test_conv_plain(ops, B, H, W, Cin, Cout, k):
     close(nchw(got), ref)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [
+    (2, 16, 16, 64, 128, 3), (1, 32, 32, 3, 64, 3), (2, 4, 4, 512, 256, 3), (4, 1, 1, 512, 1024, 3),
+    (1, 12, 20, 64, 3, 3), (2, 16, 16, 128, 384, 1), (2, 16, 16, 64, 32, 1), (5, 7, 3, 36, 40, 3), (1, 6, 10, 68, 96, 1)])
+def test_conv_bf16(ops, B, H, W, Cin, Cout, k):
+    """bf16 matrix-core variant against the fp32 oracle evaluated on bf16-rounded operands (exact products,
+    fp32 accumulation): only the summation order differs."""
+    def bf(z):
+        u = np.ascontiguousarray(z, dtype=np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=1.0 / np.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=3)
+    ref = O.conv2d(bf(x), bf(w), b, k // 2)
+    got = ops.conv(nhwc(x), w, b, bf16=True)
+    close(nchw(got), ref, 2e-5)
+    close(nchw(got), O.conv2d(x, w, b, k // 2), 2e-2)
+
+
+def test_conv_bf16_fused_prologue_epilogue(ops):
+    B, H, W, C, Co = 2, 16, 16, 64, 128
+    x = rnd(B, C, H, W, seed=4, scale=2.0) + 0.5
+    gamma, beta = rnd(C, seed=5) * 0.2 + 1, rnd(C, seed=6) * 0.1
+    w, b = rnd(Co, C, 3, 3, seed=7, scale=0.05), rnd(Co, seed=8)
+    tb, res = rnd(B, Co, seed=9), rnd(B, Co, H, W, seed=10)
+    ref = O.conv2d(O.gelu(O.group_norm(x, 8, gamma, beta)), w, b, 1) + tb[:, :, None, None] + res
+    sc, sh = ops.gn_scale_shift(nhwc(x), 8, gamma, beta)
+    got = ops.conv(nhwc(x), w, b, scale=sc, shift=sh, pro_act="gelu", tb=tb, res=nhwc(res), bf16=True)
+    close(nchw(got), ref, 2e-2)
+
+
 def test_conv_fused_norm_gelu_timebias_residual(ops):
     """conv2 of a block: GroupNorm -> GELU applied in the loader, bias + time bias + residual in the epilogue."""
     B, H, W, C, Co = 2, 16, 16, 64, 128
