@@ -59,8 +59,8 @@ __device__ __forceinline__ int acc_key(int r, int h) { return (r & 3) + 8 * (r >
 // ------------------------------------------------------------------------------------------------ pack
 template <int D>
 __global__ __launch_bounds__(256) void pack_qkv_bf16(const float* __restrict__ qkv, __bf16* __restrict__ Qp,
-                                                     unsigned char* __restrict__ KVp, int N, int NT, int C,
-                                                     float qscale) {
+                                                     unsigned char* __restrict__ KVp, float* __restrict__ Kmax,
+                                                     int N, int NT, int C, float qscale) {
   using G = AttnGeom<D>;
   __shared__ float sk[32][D + 1];
   __shared__ float sv[32][D + 1];
@@ -87,6 +87,14 @@ __global__ __launch_bounds__(256) void pack_qkv_bf16(const float* __restrict__ q
       Qp[((size_t)bh * NT * 32 + tile * 32 + tok) * G::DP + c] = (__bf16)0.f;
     }
   __syncthreads();
+  if (tid < 64) {   // largest |k|_2 of the tile (on the bf16-rounded values): upper bound of any score q.k <= |q||k|
+    float nk = 0.f;
+    if (tid < 32)
+      for (int c = 0; c < D; ++c) { float kv = (float)(__bf16)sk[tid][c]; nk = fmaf(kv, kv, nk); }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) nk = fmaxf(nk, __shfl_xor(nk, off));
+    if (tid == 0) Kmax[(size_t)bh * NT + tile] = sqrtf(nk) * 1.002f;
+  }
   unsigned char* tbase = KVp + ((size_t)bh * NT + tile) * G::TILE_BYTES;
   // K image: chunk (c, h, key) = comps 16c + 8h + j
   for (int i = tid; i < G::KC * 64; i += 256) {
@@ -122,8 +130,8 @@ constexpr float RESCALE_THR = 20.0f;   // log2 units
 
 template <int D, int QS, int TS>
 __global__ __launch_bounds__(256) void flash_bf16(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
-                                                  float* __restrict__ out, int ldo, int N, int NT, int heads,
-                                                  int nqb, int npairs) {
+                                                  const float* __restrict__ Kmax, float* __restrict__ out, int ldo,
+                                                  int N, int NT, int heads, int nqb, int npairs) {
   using G = AttnGeom<D>;
   using SG = StageGeom<D, TS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 stage buffers
@@ -156,6 +164,20 @@ __global__ __launch_bounds__(256) void flash_bf16(const __bf16* __restrict__ Qp,
     for (int c = 0; c < G::KC; ++c) qf[u][c] = *reinterpret_cast<const bf16x8*>(qp + 16 * c);
   }
 
+  // |q|_2 per query row (both lane halves hold half of the components)
+  float qn[QS], m_run[QS];
+#pragma unroll
+  for (int u = 0; u < QS; ++u) {
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < G::KC; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float v = (float)qf[u][c][j]; a = fmaf(v, v, a); }
+    a += __shfl_xor(a, 32);
+    qn[u] = sqrtf(a) * 1.002f;
+    m_run[u] = 0.f;
+  }
+
   f32x16 o[QS][G::DT], negm[QS];
   float lsum[QS];
 #pragma unroll
@@ -174,8 +196,12 @@ __global__ __launch_bounds__(256) void flash_bf16(const __bf16* __restrict__ Qp,
   const size_t total_bytes = (size_t)NT * G::TILE_BYTES;
   const int vrow = G::ONES ? (lr < D ? lr : D) : lr;     // row of the V^T slab this lane reads
 
+  float* kmax_lds = reinterpret_cast<float*>(lds + 2 * SG::STAGE_BYTES);   // [2][TS]
+  const float* gkmax = Kmax + (size_t)bh * NT;
   float4 stg[SG::CPT];
+  float stg_km = 0.f;
   auto gload = [&](int stage) {
+    if (tid < TS) stg_km = (stage * TS + tid < NT) ? gkmax[stage * TS + tid] : 0.f;
     const unsigned char* src = gkv + (size_t)stage * SG::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < SG::CPT; ++i) {
@@ -186,6 +212,7 @@ __global__ __launch_bounds__(256) void flash_bf16(const __bf16* __restrict__ Qp,
     }
   };
   auto lstore = [&](int buf) {
+    if (tid < TS) kmax_lds[buf * TS + tid] = stg_km;
     unsigned char* dst = lds + buf * SG::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < SG::CPT; ++i)
@@ -204,6 +231,7 @@ __global__ __launch_bounds__(256) void flash_bf16(const __bf16* __restrict__ Qp,
     for (int t = 0; t < tiles_here; ++t) {
       const int kt = st * TS + t;
       const unsigned char* tb = sb + t * G::TILE_BYTES;
+      const float kmx = kmax_lds[buf * TS + t];
       bf16x8 kf[G::KC];
 #pragma unroll
       for (int c = 0; c < G::KC; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(tb + c * 1024 + lane * 16);
@@ -219,29 +247,36 @@ __global__ __launch_bounds__(256) void flash_bf16(const __bf16* __restrict__ Qp,
         f32x16 s = negm[u];
 #pragma unroll
         for (int c = 0; c < G::KC; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[u][c], s, 0, 0, 0);
-        if (kt == NT - 1 && (N & 31) != 0) {   // padding keys of the last tile never win the max
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (kt * 32 + acc_key(r, lh) >= N) s[r] = -INFINITY;
-        }
-        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, s[r]), s[r + 1]);
-        tmax = fmaxf(tmax, s[15]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const bool first = (kt == 0);
-        if (first || __any(tmax > RESCALE_THR)) {
-          // raise the running max of the rows that need it (every row on the first tile)
-          const float delta = first ? tmax : (tmax > RESCALE_THR ? tmax : 0.f);
+        const bool ragged = (kt == NT - 1) && (N & 31) != 0;
+        // Cheap upper bound of every score of this tile: |q||k|max - m.  While it stays under the threshold no
+        // key can force a rescale, so the exact row max (8 v_max3 + a cross-half exchange) is skipped.
+        const float bound = fmaf(qn[u], kmx, -m_run[u]);
+        if (first || ragged || __any(bound > RESCALE_THR)) {
+          if (ragged) {   // padding keys of the last tile never win the max (and add nothing to the sums)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { s[r] -= delta; negm[u][r] -= delta; }
-          if (!first) {
-            const float f = exp2f(-delta);
-            lsum[u] *= f;
+            for (int r = 0; r < 16; ++r)
+              if (kt * 32 + acc_key(r, lh) >= N) s[r] = -INFINITY;
+          }
+          float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
-            for (int dt = 0; dt < G::DT; ++dt)
+          for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, s[r]), s[r + 1]);
+          tmax = fmaxf(tmax, s[15]);
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+          if (first || __any(tmax > RESCALE_THR)) {
+            // raise the running max of the rows that need it (every row on the first tile)
+            const float delta = first ? tmax : (tmax > RESCALE_THR ? tmax : 0.f);
+            m_run[u] += delta;
 #pragma unroll
-              for (int r = 0; r < 16; ++r) o[u][dt][r] *= f;
+            for (int r = 0; r < 16; ++r) { s[r] -= delta; negm[u][r] -= delta; }
+            if (!first) {
+              const float f = exp2f(-delta);
+              lsum[u] *= f;
+#pragma unroll
+              for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[u][dt][r] *= f;
+            }
           }
         }
         bf16x8 pb[2];
@@ -298,17 +333,19 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
   __bf16* Qp = static_cast<__bf16*>(ws);
   size_t q_bytes = ((size_t)BH * NT * 32 * G::DP * 2 + 255) & ~size_t(255);
   unsigned char* KVp = static_cast<unsigned char*>(ws) + q_bytes;
+  const size_t kv_bytes = ((size_t)BH * NT * G::TILE_BYTES + 255) & ~size_t(255);
+  float* Kmax = reinterpret_cast<float*>(KVp + kv_bytes);
   const float qscale = 1.44269504088896340736f / sqrtf((float)D);
-  hipLaunchKernelGGL(pack_qkv_bf16<D>, dim3(NT, heads, B), dim3(256), 0, s, qkv, Qp, KVp, N, NT, C, qscale);
+  hipLaunchKernelGGL(pack_qkv_bf16<D>, dim3(NT, heads, B), dim3(256), 0, s, qkv, Qp, KVp, Kmax, N, NT, C, qscale);
   const int nqb = (N + 128 * QS - 1) / (128 * QS);
   static bool attr_set = false;
   if (!attr_set) {
     DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16<D, QS, TS>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SG::STAGE_BYTES));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SG::STAGE_BYTES + 2 * TS * 4));
     attr_set = true;
   }
-  hipLaunchKernelGGL((flash_bf16<D, QS, TS>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES, s, Qp, KVp, out, ldo,
-                     N, NT, heads, nqb, BH);
+  hipLaunchKernelGGL((flash_bf16<D, QS, TS>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
+                     out, ldo, N, NT, heads, nqb, BH);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
@@ -316,7 +353,8 @@ template <int D>
 size_t ws_bytes_for(int B, int N, int heads) {
   using G = AttnGeom<D>;
   const size_t NT = (N + 31) / 32, BH = (size_t)B * heads;
-  return ((BH * NT * 32 * G::DP * 2 + 255) & ~size_t(255)) + BH * NT * G::TILE_BYTES + 256;
+  return ((BH * NT * 32 * G::DP * 2 + 255) & ~size_t(255)) + ((BH * NT * G::TILE_BYTES + 255) & ~size_t(255)) +
+         BH * NT * 4 + 256;
 }
 
 }  // namespace

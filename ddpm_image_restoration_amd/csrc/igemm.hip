@@ -12,6 +12,9 @@
 // LDS image: row-major [row][32 k + 4 pad] floats; a lane reads 16 B = 4 consecutive k of its row
 // (ds_read_b128; the 36-float row stride is conflict-free for the 16-lane b128 groups).  Within a chunk
 // the k order seen by the MFMA is permuted (lane half h takes k = 8g+4h+j) -- identical for A and B.
+#include <algorithm>
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace ddpmir {
@@ -190,10 +193,12 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int BK16 = 64;
 constexpr int LROW16 = BK16 * 2 + 16;   // bytes
 
-template <int NT>
+template <int NT, int STAGES>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
-  __shared__ __attribute__((aligned(16))) unsigned char As[BM * LROW16];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[NT * 32 * LROW16];
+  // STAGES == 2: two LDS stages: chunk i is consumed by the MFMAs while chunk i+1 is written and chunk i+2 is in flight
+  // from global memory into registers -> one barrier per chunk and a full chunk of latency cover.
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int A_BYTES = BM * LROW16, B_BYTES = NT * 32 * LROW16, STAGE = A_BYTES + B_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -205,7 +210,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * (NT * 32);
   const int nck = (p.Cin + BK16 - 1) / BK16;
-  const int nit = p.taps * nck;
+  const int nit_all = p.taps * nck;
+  // split-K: this workgroup owns iterations [it0, it1) of the (tap, chunk) space
+  const int nsplit = gridDim.z, sk = blockIdx.z;
+  const int it0 = (int)((long long)nit_all * sk / nsplit), it1 = (int)((long long)nit_all * (sk + 1) / nsplit);
+  const int nit = it1 - it0;
   const bool affine = p.scale != nullptr;
   const __bf16* Wb = reinterpret_cast<const __bf16*>(p.Wt16);
 
@@ -228,11 +237,13 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
   }
 
   float4 a_lo[4], a_hi[4];
+  float4 sc_lo, sc_hi, sh_lo, sh_hi;      // GroupNorm scale/shift of this thread's channel group, image a_b[0]
   bool a_val[4], c_lo = false, c_hi = false;
   int cur_c = 0;
   bf16x8 b_reg[NT];
 
-  auto gload = [&](int it) {
+  auto gload = [&](int itl) {
+    const int it = it0 + itl;
     int tap = it / nck;
     int c = (it - tap * nck) * BK16 + 8 * q;
     cur_c = c;
@@ -245,18 +256,24 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
       a_val[i] = ok;
       a_lo[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       a_hi[i] = a_lo[i];
-      if (ok) {
+      if (ok && !(p.dbg & 1)) {
         const float* src = p.A + a_off[i] + (ptrdiff_t)(dy * p.W + dx) * p.lda + c;
         a_lo[i] = *reinterpret_cast<const float4*>(src);
         if (c_hi) a_hi[i] = *reinterpret_cast<const float4*>(src + 4);
       }
+    }
+    if (affine && c_lo) {
+      const float* sp = p.scale + (size_t)a_b[0] * p.Cin + c;
+      const float* hp = p.shift + (size_t)a_b[0] * p.Cin + c;
+      sc_lo = *reinterpret_cast<const float4*>(sp); sh_lo = *reinterpret_cast<const float4*>(hp);
+      if (c_hi) { sc_hi = *reinterpret_cast<const float4*>(sp + 4); sh_hi = *reinterpret_cast<const float4*>(hp + 4); }
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       int n = n0 + r0 + 32 * i;
 #pragma unroll
       for (int j = 0; j < 8; ++j) b_reg[i][j] = (__bf16)0.f;
-      if (n < p.Cout && c_lo) {
+      if (n < p.Cout && c_lo && !(p.dbg & 2)) {
         const __bf16* src = Wb + ((size_t)tap * p.Cout + n) * p.Cin + c;
         if (c_hi) b_reg[i] = *reinterpret_cast<const bf16x8*>(src);
         else {
@@ -274,13 +291,16 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
     return v;
   };
 
-  auto lds_store = [&]() {
+  auto lds_store = [&](int buf) {
+    if (p.dbg & 16) return;
+    unsigned char* As = smem + buf * STAGE;
+    unsigned char* Bs = As + A_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       bf16x8 o;
       if (a_val[i]) {
-        float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, h0 = make_float4(0.f, 0.f, 0.f, 0.f), h1 = h0;
-        if (affine) {
+        float4 s0 = sc_lo, s1 = sc_hi, h0 = sh_lo, h1 = sh_hi;
+        if (affine && a_b[i] != a_b[0]) {   // tile straddles two images (rare): fetch that image's coefficients
           const float* sp = p.scale + (size_t)a_b[i] * p.Cin + cur_c;
           const float* hp = p.shift + (size_t)a_b[i] * p.Cin + cur_c;
           s0 = *reinterpret_cast<const float4*>(sp); h0 = *reinterpret_cast<const float4*>(hp);
@@ -312,27 +332,116 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
 
   const int lr = lane & 31;
   const int lh = lane >> 5;
-  const unsigned char* a_rd = &As[(wave * 32 + lr) * LROW16 + 16 * lh];
-  const unsigned char* b_rd = &Bs[lr * LROW16 + 16 * lh];
+  const int a_rd = (wave * 32 + lr) * LROW16 + 16 * lh;
+  const int b_rd = A_BYTES + lr * LROW16 + 16 * lh;
 
-  gload(0);
-  for (int it = 0; it < nit; ++it) {
-    lds_store();
+  if (STAGES == 1) {
+    // short-K layers (full-resolution 3x3 / 1x1): one LDS stage, half the LDS -> more workgroups per CU cover
+    // the load latency instead of a deeper in-workgroup pipeline
+    if (nit > 0) gload(0);
+    for (int it = 0; it < nit; ++it) {
+      lds_store(0);
+      __syncthreads();
+      if (it + 1 < nit) gload(it + 1);
+#pragma unroll
+      for (int ks = 0; ks < BK16 / 16; ++ks) {
+        bf16x8 a8 = *reinterpret_cast<const bf16x8*>(smem + a_rd + 32 * ks);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          bf16x8 b8 = *reinterpret_cast<const bf16x8*>(smem + b_rd + nt * 32 * LROW16 + 32 * ks);
+          if (!(p.dbg & 4)) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[nt], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  } else if (nit > 0) {
+    gload(0);
+    lds_store(0);
+    if (nit > 1) gload(1);
     __syncthreads();
-    if (it + 1 < nit) gload(it + 1);
+    for (int it = 0; it < nit; ++it) {
+      const unsigned char* st = smem + (it & 1) * STAGE;
 #pragma unroll
-    for (int ks = 0; ks < BK16 / 16; ++ks) {
-      bf16x8 a8 = *reinterpret_cast<const bf16x8*>(a_rd + 32 * ks);
+      for (int ks = 0; ks < BK16 / 16; ++ks) {
+        bf16x8 a8 = *reinterpret_cast<const bf16x8*>(st + a_rd + 32 * ks);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        bf16x8 b8 = *reinterpret_cast<const bf16x8*>(b_rd + nt * 32 * LROW16 + 32 * ks);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          bf16x8 b8 = *reinterpret_cast<const bf16x8*>(st + b_rd + nt * 32 * LROW16 + 32 * ks);
+          if (!(p.dbg & 4)) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[nt], 0, 0, 0);
+        }
+      }
+      if (it + 1 < nit) {
+        lds_store((it + 1) & 1);          // stage (it+1)&1 was last read in iteration it-1 (fenced by its barrier)
+        if (it + 2 < nit) gload(it + 2);
+        __syncthreads();
       }
     }
-    __syncthreads();
   }
 
   const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE || p.store == STORE_NCHW;
+  const bool atomic = nsplit > 1;
+  const bool lead = sk == 0;
+
+  if (!atomic && p.store == STORE_NHWC && (p.Cout & 3) == 0) {
+    // ---- coalesced epilogue: accumulators -> wave-private LDS tile -> 16-byte row-contiguous global accesses
+    // (4-byte-per-lane stores reach ~1 TB/s on this chip; full-line dwordx4 rows reach the HBM rate)
+    constexpr int BN = NT * 32, BNP = BN + 4;
+    __syncthreads();                                     // all waves are done with the staging buffers
+    float* ct = reinterpret_cast<float*>(smem) + wave * 32 * BNP;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + nt * 32 + lr] = acc[nt][r];
+    // wave-private region, same wave reads it back: LDS ops of one wave are ordered
+    constexpr int L4 = BN / 4;            // float4 per row
+    constexpr int RPP = 64 / L4;          // rows per pass
+    const int c4 = lane % L4, rsub = lane / L4;
+    const int n = n0 + 4 * c4;
+    if ((p.dbg & 8) && acc[0][0] != 12345.f) return;
+    if (n < p.Cout) {
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias && (!atomic || lead)) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll 4
+      for (int pass = 0; pass < 32 / RPP; ++pass) {
+        const int row = pass * RPP + rsub;
+        const int m = m0 + wave * 32 + row;
+        if (m >= M) continue;
+        float4 v = *reinterpret_cast<const float4*>(ct + row * BNP + 4 * c4);
+        int b = 0, y = 0, x = 0;
+        if (need_pos) {
+          b = m / HW;
+          int rem = m - b * HW;
+          y = rem / p.W;
+          x = rem - y * p.W;
+        }
+        float* op = p.out + (size_t)m * p.ldo + n;
+        if (atomic) {
+          if (lead) {
+            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+            if (p.tb) { float4 t = *reinterpret_cast<const float4*>(p.tb + (size_t)b * p.ldtb + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (p.res && p.res != p.out) { float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+          }
+          atomicAdd(op, v.x); atomicAdd(op + 1, v.y); atomicAdd(op + 2, v.z); atomicAdd(op + 3, v.w);
+          continue;
+        }
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (p.tb) { float4 t = *reinterpret_cast<const float4*>(p.tb + (size_t)b * p.ldtb + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (p.epi_act != ACT_NONE) { v.x = act_apply(v.x, p.epi_act); v.y = act_apply(v.y, p.epi_act); v.z = act_apply(v.z, p.epi_act); v.w = act_apply(v.w, p.epi_act); }
+        if (p.mul) { float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + n); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+        if (p.rowscale) { float rs = p.rowscale[b]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+        if (p.epi_mask != MASK_NONE) {
+          bool lowp = is_low_freq(y, x, p.H, p.W, p.bs, p.low);
+          bool keep = (p.epi_mask == MASK_LOW) ? lowp : !lowp;
+          if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        *reinterpret_cast<float4*>(op) = v;
+      }
+    }
+    return;
+  }
+
+  // ---- scalar epilogue (NCHW store of the 3-channel head, odd channel counts)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -356,6 +465,17 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
       int n = n0 + nt * 32 + lr;
       if (n >= p.Cout) continue;
       float v = acc[nt][r];
+      if (atomic) {
+        // split-K partial sums: one 256-byte row segment per wave instruction (the shape float atomics like);
+        // linear epilogue only (checked by the launcher): the lead split adds bias / time bias / residual
+        if (lead) {
+          if (p.bias) v += p.bias[n];
+          if (p.tb) v += p.tb[(size_t)b * p.ldtb + n];
+          if (p.res && p.res != p.out) v += p.res[(size_t)m * p.ldres + n];
+        }
+        atomicAdd(&p.out[(size_t)m * p.ldo + n], v);
+        continue;
+      }
       if (p.bias) v += p.bias[n];
       if (p.tb) v += p.tb[(size_t)b * p.ldtb + n];
       v = act_apply(v, p.epi_act);
@@ -369,6 +489,48 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
   }
 }
 
+// zero an [M][C] slice of a strided tensor (split-K accumulation target)
+__global__ void zero_rows_k(float* out, int ldo, int64_t M, int C4) {
+  const int64_t total = M * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t m = i / C4;
+    int c4 = (int)(i - m * C4);
+    *reinterpret_cast<float4*>(out + m * ldo + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int NT>
+void launch_bf16(const IGemm& p, int64_t M, hipStream_t stream) {
+  constexpr int EPI = 4 * 32 * (NT * 32 + 4) * 4;                      // epilogue staging tile
+  constexpr int LDS1 = (BM + NT * 32) * LROW16 > EPI ? (BM + NT * 32) * LROW16 : EPI;
+  constexpr int LDS = 2 * (BM + NT * 32) * LROW16;
+  static bool attr = false;
+  if (!attr) {
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_kernel<NT, 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_kernel<NT, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS1));
+    attr = true;
+  }
+  const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
+  const int nit = p.taps * cdiv(p.Cin, BK16);
+  // split K across workgroups when the output tiling alone cannot fill the 256 CUs and the epilogue is linear
+  int nsplit = 1;
+  const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE &&
+                      p.store == STORE_NHWC && (p.Cout % 4) == 0 && (!p.res || p.res != p.out || p.ldres == p.ldo);
+  if (linear && gx * gy < 256 && nit >= 8) {
+    nsplit = std::min(std::min(16, nit / 4), cdiv(512, gx * gy));
+    if (nsplit < 1) nsplit = 1;
+  }
+  if (nsplit > 1 && !(p.res && p.res == p.out))
+    hipLaunchKernelGGL(zero_rows_k, dim3((unsigned)std::min<int64_t>(cdiv64(M * (p.Cout / 4), 256), 2048)), dim3(256), 0,
+                       stream, p.out, p.ldo, M, p.Cout / 4);
+  static const int force = [] { const char* e = getenv("DDPMIR_IGEMM_STAGES"); return e ? atoi(e) : 0; }();
+  const bool one = force ? force == 1 : (nit <= 18 && nsplit == 1);
+  if (one) hipLaunchKernelGGL((igemm_bf16_kernel<NT, 1>), dim3(gx, gy, 1), dim3(256), LDS1, stream, p);
+  else hipLaunchKernelGGL((igemm_bf16_kernel<NT, 2>), dim3(gx, gy, nsplit), dim3(256), LDS, stream, p);
+}
+
 }  // namespace
 
 void launch_igemm(const IGemm& p, hipStream_t stream) {
@@ -379,9 +541,9 @@ void launch_igemm(const IGemm& p, hipStream_t stream) {
   if (M <= 0 || p.Cout <= 0) return;
   dim3 block(256);
   if (p.Wt16) {
-    if (p.Cout <= 32) hipLaunchKernelGGL(igemm_bf16_kernel<1>, dim3((unsigned)cdiv64(M, BM), 1), block, 0, stream, p);
-    else if (p.Cout <= 64) hipLaunchKernelGGL(igemm_bf16_kernel<2>, dim3((unsigned)cdiv64(M, BM), 1), block, 0, stream, p);
-    else hipLaunchKernelGGL(igemm_bf16_kernel<4>, dim3((unsigned)cdiv64(M, BM), (unsigned)cdiv(p.Cout, 128)), block, 0, stream, p);
+    if (p.Cout <= 32) launch_bf16<1>(p, M, stream);
+    else if (p.Cout <= 64) launch_bf16<2>(p, M, stream);
+    else launch_bf16<4>(p, M, stream);
     DDPMIR_HIP_CHECK(hipGetLastError());
     return;
   }

@@ -30,6 +30,7 @@ struct IGemm {
   const float* res = nullptr; int ldres = 0;
   // output
   float* out = nullptr; int ldo = 0; int store = STORE_NHWC;
+  int dbg = 0;   // timing experiments only: 1 skip A loads, 2 skip B loads, 4 skip MFMA, 8 skip stores, 16 skip LDS writes
 };
 void launch_igemm(const IGemm& p, hipStream_t stream);
 

@@ -101,6 +101,49 @@ int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_
   });
 }
 
+int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int bf16, int gelu_norm, int residual,
+                        int dbg, int iters, float* ms_per_call) {
+  return guarded([&] {
+    Dev d;
+    const int taps = ksize * ksize;
+    const size_t M = (size_t)B * H * W;
+    float* x = d.alloc<float>(M * Cin + 4);
+    launch_randn(x, (int64_t)(M * Cin), 11, 0, nullptr);
+    float* w = d.alloc<float>((size_t)taps * Cout * Cin + 4);
+    launch_randn(w, (int64_t)taps * Cout * Cin, 12, 0, nullptr);
+    std::vector<float> wh((size_t)taps * Cout * Cin);
+    d.down(wh.data(), w, wh.size());
+    std::vector<unsigned short> w16(wh.size());
+    for (size_t i = 0; i < wh.size(); ++i) {
+      unsigned int u;
+      memcpy(&u, &wh[i], 4);
+      w16[i] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    }
+    IGemm p;
+    p.A = x; p.lda = Cin; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Wt = w; p.Cout = Cout; p.taps = taps;
+    if (bf16) p.Wt16 = d.up(w16.data(), w16.size());
+    std::vector<float> ones((size_t)B * Cin, 1.0f), zeros((size_t)B * Cin, 0.1f), bias(Cout, 0.01f);
+    p.bias = d.up(bias.data(), bias.size());
+    if (gelu_norm) { p.scale = d.up(ones.data(), ones.size()); p.shift = d.up(zeros.data(), zeros.size()); p.pro_act = ACT_GELU; }
+    float* o = d.alloc<float>(M * Cout);
+    if (residual) { p.res = o; p.ldres = Cout; }
+    p.out = o; p.ldo = Cout; p.dbg = dbg;
+    hipEvent_t a, b;
+    DDPMIR_HIP_CHECK(hipEventCreate(&a));
+    DDPMIR_HIP_CHECK(hipEventCreate(&b));
+    launch_igemm(p, nullptr);
+    DDPMIR_HIP_CHECK(hipDeviceSynchronize());
+    DDPMIR_HIP_CHECK(hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) launch_igemm(p, nullptr);
+    DDPMIR_HIP_CHECK(hipEventRecord(b, nullptr));
+    DDPMIR_HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0.f;
+    DDPMIR_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    *ms_per_call = ms / iters;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  });
+}
+
 int ddpmir_op_gn_scale_shift(const float* x, int B, int HW, int C, int G, const float* gamma, const float* beta,
                              float* scale, float* shift) {
   return guarded([&] {

@@ -10,7 +10,8 @@ namespace {
 // Pass 1: a workgroup streams a contiguous run of pixels of ONE image, all channels (fully coalesced),
 // every thread owns a fixed 4-channel slot -> one group; double partial sums per (b, split, g).
 // Pass 2: fold the splits, emit scale = rstd*gamma, shift = beta - mean*scale per (b, c).
-constexpr int GN_PIX_PER_SPLIT = 2048;
+constexpr int GN_PIX_PER_SPLIT = 256;
+constexpr int GN_MAX_SPLITS = 512;
 
 __global__ __launch_bounds__(256) void gn_partial(const float* __restrict__ x, int ldx, int HW, int C, int G,
                                                   int splits, double* __restrict__ partial) {
@@ -30,7 +31,23 @@ __global__ __launch_bounds__(256) void gn_partial(const float* __restrict__ x, i
     if (pslot < pix_per_iter) {
       g = (slot * vec) / cpg;
       const float* xb = x + (size_t)b * HW * ldx + slot * vec;
-      for (int64_t p = p_begin + pslot; p < p_end; p += pix_per_iter) {
+      int64_t p = p_begin + pslot;
+      if (vec == 4) {
+        // 4 independent loads in flight per thread; fp32 partials of 4 values, folded into fp64 per pixel
+        double b1 = 0.0, b2 = 0.0, c1 = 0.0, c2 = 0.0, d1 = 0.0, d2 = 0.0;
+        for (; p + 3 * (int64_t)pix_per_iter < p_end; p += 4 * (int64_t)pix_per_iter) {
+          float4 v0 = *reinterpret_cast<const float4*>(xb + p * ldx);
+          float4 v1 = *reinterpret_cast<const float4*>(xb + (p + pix_per_iter) * ldx);
+          float4 v2 = *reinterpret_cast<const float4*>(xb + (p + 2 * (int64_t)pix_per_iter) * ldx);
+          float4 v3 = *reinterpret_cast<const float4*>(xb + (p + 3 * (int64_t)pix_per_iter) * ldx);
+          a1 += (double)((v0.x + v0.y) + (v0.z + v0.w)); a2 += (double)v0.x * v0.x + (double)v0.y * v0.y + (double)v0.z * v0.z + (double)v0.w * v0.w;
+          b1 += (double)((v1.x + v1.y) + (v1.z + v1.w)); b2 += (double)v1.x * v1.x + (double)v1.y * v1.y + (double)v1.z * v1.z + (double)v1.w * v1.w;
+          c1 += (double)((v2.x + v2.y) + (v2.z + v2.w)); c2 += (double)v2.x * v2.x + (double)v2.y * v2.y + (double)v2.z * v2.z + (double)v2.w * v2.w;
+          d1 += (double)((v3.x + v3.y) + (v3.z + v3.w)); d2 += (double)v3.x * v3.x + (double)v3.y * v3.y + (double)v3.z * v3.z + (double)v3.w * v3.w;
+        }
+        a1 += b1 + c1 + d1; a2 += b2 + c2 + d2;
+      }
+      for (; p < p_end; p += pix_per_iter) {
         if (vec == 4) {
           float4 v = *reinterpret_cast<const float4*>(xb + p * ldx);
           a1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
@@ -164,10 +181,17 @@ __global__ void adaptive_avgpool_k(const float* __restrict__ in, int ldi, float*
 
 // ------------------------------------------------------------------------------------------- block transform
 // One thread = one (block, channel): Y = T X T^T with zero padding beyond H/W and cropping on store.
+// The transform matrix sits in LDS (shared matrix) or is streamed per channel; X lives in registers with
+// compile-time indexing only (a runtime-indexed local array would be demoted to scratch memory).
 template <int BS>
-__global__ void block_transform_k(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B,
+__global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_k(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B,
                                   int H, int W, int C, const float* __restrict__ mats, int per_channel,
                                   float mix_in, float mix_t) {
+  __shared__ float Ts[BS * BS];
+  if (!per_channel) {
+    for (int i = threadIdx.x; i < BS * BS; i += blockDim.x) Ts[i] = mats[i];
+    __syncthreads();
+  }
   const int nby = (H + BS - 1) / BS, nbx = (W + BS - 1) / BS;
   const int64_t total = (int64_t)B * nby * nbx * C;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -175,12 +199,8 @@ __global__ void block_transform_k(const float* __restrict__ in, int ldi, float* 
     int64_t p = i / C;
     int bx = p % nbx; p /= nbx;
     int by = p % nby; int b = p / nby;
-    const float* T = mats + (per_channel ? (size_t)c * BS * BS : 0);
-    float X[BS][BS], Tm[BS][BS], tmp[BS][BS];
-#pragma unroll
-    for (int u = 0; u < BS; ++u)
-#pragma unroll
-      for (int v = 0; v < BS; ++v) Tm[u][v] = T[u * BS + v];
+    const float* T = per_channel ? mats + (size_t)c * BS * BS : Ts;
+    float X[BS][BS];
 #pragma unroll
     for (int u = 0; u < BS; ++u) {
       int y = by * BS + u;
@@ -190,26 +210,34 @@ __global__ void block_transform_k(const float* __restrict__ in, int ldi, float* 
         X[u][v] = (y < H && x < W) ? in[(((size_t)b * H + y) * W + x) * ldi + c] : 0.f;
       }
     }
-    // tmp = T X
-#pragma unroll
-    for (int u = 0; u < BS; ++u)
-#pragma unroll
-      for (int v = 0; v < BS; ++v) {
-        float a = 0.f;
-#pragma unroll
-        for (int k = 0; k < BS; ++k) a = fmaf(Tm[u][k], X[k][v], a);
-        tmp[u][v] = a;
-      }
-    // Y = tmp T^T
+    // tmp = T X   (row u of tmp needs row u of T: read it once)
+    float tmp[BS][BS];
 #pragma unroll
     for (int u = 0; u < BS; ++u) {
-      int y = by * BS + u;
+      float tr[BS];
+#pragma unroll
+      for (int k = 0; k < BS; ++k) tr[k] = T[u * BS + k];
 #pragma unroll
       for (int v = 0; v < BS; ++v) {
-        int x = bx * BS + v;
         float a = 0.f;
 #pragma unroll
-        for (int k = 0; k < BS; ++k) a = fmaf(tmp[u][k], Tm[v][k], a);
+        for (int k = 0; k < BS; ++k) a = fmaf(tr[k], X[k][v], a);
+        tmp[u][v] = a;
+      }
+    }
+    // Y = tmp T^T : Y[u][v] = sum_k tmp[u][k] * T[v][k]
+#pragma unroll
+    for (int v = 0; v < BS; ++v) {
+      float tr[BS];
+#pragma unroll
+      for (int k = 0; k < BS; ++k) tr[k] = T[v * BS + k];
+      int x = bx * BS + v;
+#pragma unroll
+      for (int u = 0; u < BS; ++u) {
+        int y = by * BS + u;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < BS; ++k) a = fmaf(tmp[u][k], tr[k], a);
         if (y < H && x < W) out[(((size_t)b * H + y) * W + x) * ldo + c] = mix_in * X[u][v] + mix_t * a;
       }
     }
@@ -318,7 +346,7 @@ int gn_splits(int HW, int C) {
   (void)C;
   int s = cdiv(HW, GN_PIX_PER_SPLIT);
   if (s < 1) s = 1;
-  if (s > 64) s = 64;
+  if (s > GN_MAX_SPLITS) s = GN_MAX_SPLITS;
   return s;
 }
 

@@ -14,6 +14,7 @@ _sigs = {
     "ddpmir_op_conv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int,
                                  C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P]),
     "ddpmir_op_set_bf16": (None, [C.c_int]),
+    "ddpmir_op_conv_time": (C.c_int, [C.c_int] * 11 + [C.POINTER(C.c_float)]),
     "ddpmir_op_gn_scale_shift": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "ddpmir_op_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ddpmir_op_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
@@ -78,6 +79,14 @@ def conv(x, w, bias=None, scale=None, shift=None, pro_act=None, pro_mask=None, b
                             _p(res), int(nchw_out), _p(out))
     _chk(lib, rc, "op_conv")
     return out
+
+
+def conv_time(b, h, w, cin, cout, k, bf16=True, gelu_norm=False, residual=False, dbg=0, iters=5):
+    lib = _lib_ops()
+    ms = C.c_float(0)
+    _chk(lib, lib.ddpmir_op_conv_time(b, h, w, cin, cout, k, int(bf16), int(gelu_norm), int(residual), dbg, iters,
+                                      C.byref(ms)), "op_conv_time")
+    return ms.value
 
 
 def gn_scale_shift(x, groups, gamma, beta):

@@ -24,6 +24,10 @@ int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_
                    const float* res, int nchw_out, float* out);
 /* select the bf16 matrix-core variant for subsequent ddpmir_op_conv calls of this thread (0 = fp32) */
 void ddpmir_op_set_bf16(int enable);
+/* device-resident timing of one conv/linear launch on random data (ms per call); gelu_norm adds the fused
+ * GroupNorm+GELU prologue; dbg is a kernel-internal experiment mask (0 in normal use) */
+int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int bf16, int gelu_norm, int residual,
+                        int dbg, int iters, float* ms_per_call);
 
 /* nn.GroupNorm statistics folded to per-(b,c) scale/shift (webp_inference.py:281); x [B,HW,C]. */
 int ddpmir_op_gn_scale_shift(const float* x, int B, int HW, int C, int G, const float* gamma, const float* beta,
