@@ -137,8 +137,10 @@ int ddpmir_p_sample_loop(ddpmir_ctx* ctx, const float*, float*, int, int, int, i
   if (ctx) ctx->err = "p_sample_loop: not built in this version";
   return DDPMIR_ESTATE;
 }
-int ddpmir_jpeg_roundtrip_u8(ddpmir_ctx* ctx, const uint8_t*, uint8_t*, int, int, int, int) {
-  if (ctx) ctx->err = "jpeg_roundtrip_u8: not built in this version";
-  return DDPMIR_ESTATE;
+int ddpmir_jpeg_roundtrip_u8(ddpmir_ctx* ctx, const uint8_t* in, uint8_t* out, int B, int H, int W, int quality) {
+  return guarded(ctx, [&] {
+    if (!in || !out) throw std::invalid_argument("jpeg_roundtrip_u8: null pointer");
+    ctx->impl->jpeg_roundtrip(in, out, B, H, W, quality);
+  });
 }
 }

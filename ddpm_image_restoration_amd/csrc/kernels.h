@@ -97,6 +97,11 @@ void launch_fill_t(float* t, int B, int step_i, int steps, hipStream_t s);
 // Philox4x32-10 + Box-Muller standard normal, counter = global element index (independent of GPU count)
 void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s);
 
+// on-device JPEG encode->decode round trip, bit-exact to libjpeg-turbo/Pillow defaults (jpeg_sim.hip)
+size_t jpeg_sim_workspace(int B, int H, int W);
+void launch_jpeg_roundtrip(const uint8_t* in, uint8_t* out, uint8_t* scratch, int B, int H, int W, int quality,
+                           hipStream_t s);
+
 // phase_consistency (webp_inference.py:531-550) on NCHW planes via separable DFTs.
 struct DftPlan {           // device twiddle tables
   const float* cos_h; const float* sin_h; int H;

@@ -80,6 +80,7 @@ class Context {
   void ddrm_sample_loop(const float* y, float* out, int B, int H, int W, int quality, int steps, double eta,
                         double eta_b, const ddpmir_loop_opts* opts);
   void phase_consistency(const float* x, const float* ref, float* out, int B, int H, int W, double alpha);
+  void jpeg_roundtrip(const uint8_t* in, uint8_t* out, int B, int H, int W, int quality);
   void profile_enable(int enable);
   void profile_read(const std::string& cls, double* ms, int64_t* launches, double* flops);
 
@@ -118,7 +119,7 @@ class Context {
     float *boost = nullptr, *boost2 = nullptr, *constmix = nullptr;
     // sampler state
     float *s_xt = nullptr, *s_theta = nullptr, *s_y = nullptr, *s_noise = nullptr, *s_t = nullptr;
-    uint8_t *s_u8 = nullptr, *s_dec = nullptr;
+    uint8_t *s_u8 = nullptr, *s_dec = nullptr, *s_jpeg = nullptr;
     float* dft[10] = {nullptr};
     float *tw_ch = nullptr, *tw_sh = nullptr, *tw_cw = nullptr, *tw_sw = nullptr;
     // graph

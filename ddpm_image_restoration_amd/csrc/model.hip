@@ -267,6 +267,7 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
   p.s_xt = a.take<float>(n_img); p.s_theta = a.take<float>(n_img); p.s_y = a.take<float>(n_img);
   p.s_noise = a.take<float>(n_img + 4); p.s_t = a.take<float>(B);
   p.s_u8 = a.take<uint8_t>(n_img); p.s_dec = a.take<uint8_t>(n_img);
+  p.s_jpeg = a.take<uint8_t>(jpeg_sim_workspace(B, H, W));
   for (int i = 0; i < 10; ++i) p.dft[i] = a.take<float>(n_img);
   p.tw_ch = a.take<float>(H); p.tw_sh = a.take<float>(H); p.tw_cw = a.take<float>(W); p.tw_sw = a.take<float>(W);
   p.g_x = a.take<float>(n_img); p.g_out = a.take<float>(n_img); p.g_t = a.take<float>(B); p.g_cl = a.take<float>(B);
@@ -598,12 +599,22 @@ void Context::phase_consistency(const float* x, const float* ref, float* out, in
   DDPMIR_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
+void Context::jpeg_roundtrip(const uint8_t* in, uint8_t* out, int B, int H, int W, int quality) {
+  DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
+  ensure_plan(B, H, W);
+  launch_jpeg_roundtrip(in, out, plan_.s_jpeg, B, H, W, quality, stream_);
+  DDPMIR_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
 // ------------------------------------------------------------------------------------------------ DDRM loop
 void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, int quality, int steps, double eta,
                                double eta_b, const ddpmir_loop_opts* opts) {
   if (!finalized_) throw std::logic_error("sample before finalize_weights");
   if (steps <= 0) throw std::invalid_argument("steps must be positive");
-  if (!opts || !opts->codec) throw std::invalid_argument("a codec callback is required (no built-in codec for this model family)");
+  if (!opts) throw std::invalid_argument("loop options are required");
+  const bool dev_codec = opts->codec == nullptr;
+  if (dev_codec && cfg.arch != DDPMIR_ARCH_JPEG)
+    throw std::invalid_argument("a codec callback is required: only the JPEG family has a built-in device codec");
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
   ensure_plan(B, H, W);
   Plan& p = plan_;
@@ -630,11 +641,16 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
       forward(p.s_xt, p.s_t, p.s_t, p.s_theta, s);
     }
     launch_quantize_u8(p.s_theta, p.s_u8, (int64_t)n, s);
-    DDPMIR_HIP_CHECK(hipMemcpyAsync(pin_in_, p.s_u8, n, hipMemcpyDeviceToHost, s));
-    DDPMIR_HIP_CHECK(hipStreamSynchronize(s));
-    int rc = opts->codec(opts->codec_user, pin_in_, pin_out_, B, H, W, quality);
-    if (rc != 0) throw std::runtime_error("codec callback failed with code " + std::to_string(rc));
-    DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_dec, pin_out_, n, hipMemcpyHostToDevice, s));
+    if (dev_codec) {
+      // JPEG round trip stays on the device: no PCIe hop, no host synchronisation inside the loop
+      launch_jpeg_roundtrip(p.s_u8, p.s_dec, p.s_jpeg, B, H, W, quality, s);
+    } else {
+      DDPMIR_HIP_CHECK(hipMemcpyAsync(pin_in_, p.s_u8, n, hipMemcpyDeviceToHost, s));
+      DDPMIR_HIP_CHECK(hipStreamSynchronize(s));
+      int rc = opts->codec(opts->codec_user, pin_in_, pin_out_, B, H, W, quality);
+      if (rc != 0) throw std::runtime_error("codec callback failed with code " + std::to_string(rc));
+      DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_dec, pin_out_, n, hipMemcpyHostToDevice, s));
+    }
     const float* noise = nullptr;
     if (i > 0) {
       if (opts->noise) noise = opts->noise + (size_t)i * n;

@@ -49,7 +49,8 @@ class _DDRMSampler:
         out = torch.empty_like(x)
         opts = _lib.LoopOpts()
         cb = self._codec_cb()
-        use_dev = bool(device_codec)
+        # JPEG has a bit-exact device codec (no host round trip); WebP / AVIF always call back into Pillow
+        use_dev = (self.KIND == "jpeg") if device_codec is None else bool(device_codec)
         opts.codec = _lib.CODEC_FN(0) if (use_dev and self.KIND == "jpeg") else cb
         opts.codec_user = None
         nz = None
@@ -104,4 +105,17 @@ def phase_consistency(model, x, ref, alpha=0.7):
     torch.cuda.current_stream(model.device).synchronize()
     rc = lib.ddpmir_phase_consistency(model._ctx, x.data_ptr(), ref.data_ptr(), out.data_ptr(), b, h, w, float(alpha))
     _lib.check(lib, model._ctx, rc, "phase_consistency")
+    return out
+
+
+def jpeg_roundtrip_device(model, u8_nchw, quality):
+    """decode(encode(img)) of a uint8 [B,3,H,W] CUDA tensor with the on-device libjpeg-turbo simulator."""
+    import torch
+    lib = _lib.load()
+    x = u8_nchw.to(model.device, torch.uint8).contiguous()
+    out = torch.empty_like(x)
+    b, c, h, w = x.shape
+    torch.cuda.current_stream(model.device).synchronize()
+    rc = lib.ddpmir_jpeg_roundtrip_u8(model._ctx, x.data_ptr(), out.data_ptr(), b, h, w, int(quality))
+    _lib.check(lib, model._ctx, rc, "jpeg_roundtrip_u8")
     return out

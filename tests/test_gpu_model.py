@@ -161,3 +161,35 @@ def test_error_paths(models):
         m.load_state_dict({"bogus": np.zeros(3, np.float32)})
     with pytest.raises(RuntimeError):
         models(spec.ARCH_WEBP)(torch.zeros(1, 3, 40, 40).cuda(), torch.zeros(1).cuda())   # not a multiple of 32
+
+
+@pytest.mark.parametrize("quality", [1, 5, 10, 20, 30, 31, 50, 75, 90, 100])
+def test_device_jpeg_bit_exact_vs_pillow(quality, models):
+    """8(f)1: the on-device JPEG round trip must equal Pillow/libjpeg-turbo bit for bit (both subsamplings)."""
+    import torch
+    from ddpm_image_restoration_amd.sampler import jpeg_roundtrip_device
+    m = models(spec.ARCH_JPEG)
+    rng = np.random.default_rng(quality)
+    imgs = [O.to_u8(synth.synth_images(2, 64, seed=quality)),                   # smooth field
+            rng.integers(0, 256, (2, 3, 32, 96), dtype=np.uint8),               # white noise, non-square
+            O.to_u8(synth.synth_images(1, 256, seed=99)),                       # bench size
+            np.zeros((1, 3, 32, 32), np.uint8), np.full((1, 3, 32, 32), 255, np.uint8)]
+    sat = rng.integers(0, 2, (1, 3, 64, 64)).astype(np.uint8) * 255            # saturated checker noise
+    for u8 in imgs + [sat]:
+        got = jpeg_roundtrip_device(m, torch.from_numpy(u8), quality).cpu().numpy()
+        ref = O.codec_u8(u8, quality, "jpeg")
+        assert np.array_equal(got, ref), (quality, u8.shape, int(np.abs(got.astype(int) - ref.astype(int)).max()))
+
+
+def test_sampler_device_codec_equals_host_codec(models, golden):
+    """The DDRM loop with the device JPEG codec produces exactly what the Pillow callback path produces."""
+    from ddpm_image_restoration_amd.sampler import DDRMJPEGSampler
+    g = golden("jpeg")
+    m = models(spec.ARCH_JPEG)
+    noise = tt(synth.synth_noise(6, 2, 32, 32, seed=8))
+    s = DDRMJPEGSampler(m)
+    for q in (10, 50):
+        y = tt(O.compress(g["samp_x0"][:2], q, "jpeg"))
+        a = s.sample(y, q, steps=6, noise=noise, device_codec=False).cpu().numpy()
+        b = s.sample(y, q, steps=6, noise=noise, device_codec=True).cpu().numpy()
+        assert np.array_equal(a, b), q
