@@ -69,8 +69,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--quality", type=int, default=10)
     ap.add_argument("--attn", choices=["all", "bottleneck"], default="all")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
-    ap.add_argument("--codec", choices=["host", "device"], default="host")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16")
+    ap.add_argument("--codec", choices=["host", "device"], default="device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full", action="store_true", help="time one complete T-step restoration instead of a slice")
     args = ap.parse_args()
@@ -148,7 +148,8 @@ def main():
                                    "step = one reverse-diffusion timestep (U-Net forward + codec round trip + DDRM update)"
                                    % (R, R, B, T_STEPS, q),
                        "global_batch": n_total, "image": R, "T": T_STEPS, "quality": q, "attn_levels": args.attn,
-                       "codec": "device JPEG simulator" if dev_codec else "host Pillow/libjpeg-turbo callback",
+                       "codec": "device JPEG round trip (bit-exact to libjpeg-turbo)" if dev_codec else "host Pillow/libjpeg-turbo callback",
+                       "arithmetic": "bf16 matrix-core operands, fp32 accumulation/softmax/GroupNorm statistics, fp32 activations in HBM" if args.dtype == "bf16" else "fp32 matrix cores",
                        "parallelism": f"dp{env.world} (independent image shards, no collective in the loop)"},
         }
         if roof:

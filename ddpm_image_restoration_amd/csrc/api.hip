@@ -3,12 +3,14 @@
 #include <stdexcept>
 #include <string>
 
+#include "eps_unet.h"
 #include "model.h"
 
 using ddpmir::Context;
 
 struct ddpmir_ctx {
-  Context* impl = nullptr;
+  Context* impl = nullptr;          // restoration U-Net context, or
+  ddpmir::EpsUnet* eps = nullptr;   // eps-predict UNetDenoiser context
   std::string err;
 };
 
@@ -16,8 +18,11 @@ namespace {
 thread_local std::string g_create_err;
 
 template <typename F>
-int guarded(ddpmir_ctx* c, F&& f) {
-  if (!c || !c->impl) return DDPMIR_EINVAL;
+int guarded(ddpmir_ctx* c, F&& f, bool want_eps = false) {
+  if (!c || (want_eps ? !c->eps : !c->impl)) {
+    if (c) c->err = want_eps ? "not an eps-UNet context" : "not a restoration-model context";
+    return DDPMIR_EINVAL;
+  }
   try {
     f();
     return DDPMIR_OK;
@@ -59,6 +64,7 @@ ddpmir_ctx* ddpmir_create(const ddpmir_config* cfg) {
 
 void ddpmir_destroy(ddpmir_ctx* ctx) {
   if (!ctx) return;
+  delete ctx->eps;
   delete ctx->impl;
   delete ctx;
 }
@@ -66,10 +72,12 @@ void ddpmir_destroy(ddpmir_ctx* ctx) {
 const char* ddpmir_last_error(ddpmir_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int ddpmir_load_tensor(ddpmir_ctx* ctx, const char* name, const float* data_host, const int64_t* shape, int ndim) {
+  const bool e = ctx && ctx->eps;
   return guarded(ctx, [&] {
     if (!name || !data_host || !shape || ndim < 0 || ndim > 8) throw std::invalid_argument("load_tensor: bad argument");
-    ctx->impl->load_tensor(name, data_host, shape, ndim);
-  });
+    if (e) ctx->eps->load_tensor(name, data_host, shape, ndim);
+    else ctx->impl->load_tensor(name, data_host, shape, ndim);
+  }, e);
 }
 
 size_t ddpmir_weight_blob_bytes(ddpmir_ctx* ctx) {
@@ -79,7 +87,11 @@ size_t ddpmir_weight_blob_bytes(ddpmir_ctx* ctx) {
 }
 
 int ddpmir_finalize_weights(ddpmir_ctx* ctx, void* dev_blob, int fill) {
-  return guarded(ctx, [&] { ctx->impl->finalize_weights(dev_blob, fill); });
+  const bool e = ctx && ctx->eps;
+  return guarded(ctx, [&] {
+    if (e) ctx->eps->finalize();
+    else ctx->impl->finalize_weights(dev_blob, fill);
+  }, e);
 }
 
 int64_t ddpmir_param_count(ddpmir_ctx* ctx) { return (ctx && ctx->impl) ? ctx->impl->param_count() : -1; }
@@ -123,24 +135,39 @@ const char* ddpmir_version(void) { return "ddpmir 0.1.0 (gfx950)"; }
 
 }  // extern "C"
 
-// ---- entry points whose device implementation is still host-stubbed return DDPMIR_ESTATE with a message
 extern "C" {
-ddpmir_ctx* ddpmir_create_eps_unet(int) {
-  g_create_err = "eps-UNet context: not built in this version";
-  return nullptr;
+
+ddpmir_ctx* ddpmir_create_eps_unet(int device) {
+  try {
+    auto* c = new ddpmir_ctx();
+    c->eps = new ddpmir::EpsUnet(device);
+    return c;
+  } catch (const std::exception& e) {
+    g_create_err = e.what();
+    return nullptr;
+  }
 }
-int ddpmir_predict_noise(ddpmir_ctx* ctx, const float*, float, float*, int, int, int) {
-  if (ctx) ctx->err = "predict_noise: not built in this version";
-  return DDPMIR_ESTATE;
+
+int ddpmir_predict_noise(ddpmir_ctx* ctx, const float* x, float t, float* eps, int B, int H, int W) {
+  return guarded(ctx, [&] {
+    if (!x || !eps) throw std::invalid_argument("predict_noise: null pointer");
+    ctx->eps->predict_sync(x, t, eps, B, H, W);
+  }, true);
 }
-int ddpmir_p_sample_loop(ddpmir_ctx* ctx, const float*, float*, int, int, int, int, const float*, int) {
-  if (ctx) ctx->err = "p_sample_loop: not built in this version";
-  return DDPMIR_ESTATE;
+
+int ddpmir_p_sample_loop(ddpmir_ctx* ctx, const float* x, float* out, int B, int H, int W, int T,
+                         const float* betas_host, int n_betas) {
+  return guarded(ctx, [&] {
+    if (!x || !out || !betas_host) throw std::invalid_argument("p_sample_loop: null pointer");
+    ctx->eps->p_sample_loop(x, out, B, H, W, T, betas_host, n_betas);
+  }, true);
 }
-int ddpmir_jpeg_roundtrip_u8(ddpmir_ctx* ctx, const uint8_t* in, uint8_t* out, int B, int H, int W, int quality) {
+
+}  // extern "C"
+
+extern "C" int ddpmir_jpeg_roundtrip_u8(ddpmir_ctx* ctx, const uint8_t* in, uint8_t* out, int B, int H, int W, int quality) {
   return guarded(ctx, [&] {
     if (!in || !out) throw std::invalid_argument("jpeg_roundtrip_u8: null pointer");
     ctx->impl->jpeg_roundtrip(in, out, B, H, W, quality);
   });
-}
 }

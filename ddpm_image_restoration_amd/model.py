@@ -177,3 +177,82 @@ def load_checkpoint(model: _RestorationModel, path: str):
     sd = ckpt["model_state_dict"] if isinstance(ckpt, dict) and "model_state_dict" in ckpt else ckpt
     model.load_state_dict(OrderedDict(sd))
     return model
+
+
+class UNetDenoiser:
+    """eps-predict denoiser of the early experiments (experiments/code/conv.ipynb c0:55-101): `net(x, t)` returns
+    the predicted noise; `ddpm_inference` / p_sample_loop is the deterministic posterior-mean loop (c1:117-125)."""
+
+    def __init__(self, device=None):
+        import torch
+        self._lib = _lib.load()
+        self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+        self._ctx = self._lib.ddpmir_create_eps_unet(self.device.index or 0)
+        if not self._ctx:
+            raise RuntimeError("ddpmir_create_eps_unet failed: " + self._lib.ddpmir_last_error(None).decode())
+        self._loaded = False
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def load_state_dict(self, state, strict=True):
+        want = spec.eps_unet_spec()
+        if strict and set(want) != set(state):
+            raise RuntimeError("state_dict mismatch for UNetDenoiser")
+        for name in want:
+            v = state[name]
+            arr = v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, dtype=np.float32)
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            if tuple(arr.shape) != tuple(want[name]):
+                raise RuntimeError(f"shape mismatch for {name}")
+            shape = (C.c_int64 * arr.ndim)(*arr.shape)
+            rc = self._lib.ddpmir_load_tensor(self._ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim)
+            _lib.check(self._lib, self._ctx, rc, f"load_tensor({name})")
+        _lib.check(self._lib, self._ctx, self._lib.ddpmir_finalize_weights(self._ctx, None, 1), "finalize_weights")
+        self._loaded = True
+        return self
+
+    def __call__(self, x, t):
+        """x [B,3,H,W] in [0,1]; t: python number or 1-element tensor (the reference passes [[t]])."""
+        import torch
+        x = x.to(self.device, torch.float32).contiguous()
+        out = torch.empty_like(x)
+        tv = float(t.reshape(-1)[0].item()) if hasattr(t, "reshape") else float(t)
+        b, c, h, w = x.shape
+        torch.cuda.current_stream(self.device).synchronize()
+        rc = self._lib.ddpmir_predict_noise(self._ctx, x.data_ptr(), tv, out.data_ptr(), b, h, w)
+        _lib.check(self._lib, self._ctx, rc, "predict_noise")
+        return out
+
+    predict_noise = __call__
+
+    def p_sample_loop(self, x, T, betas):
+        import torch
+        x = x.to(self.device, torch.float32).contiguous()
+        out = torch.empty_like(x)
+        bt = np.ascontiguousarray(betas.detach().cpu().numpy() if hasattr(betas, "detach") else betas, dtype=np.float32)
+        b, c, h, w = x.shape
+        torch.cuda.current_stream(self.device).synchronize()
+        rc = self._lib.ddpmir_p_sample_loop(self._ctx, x.data_ptr(), out.data_ptr(), b, h, w, int(T),
+                                            bt.ctypes.data_as(C.c_void_p), int(bt.size))
+        _lib.check(self._lib, self._ctx, rc, "p_sample_loop")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self._lib.ddpmir_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+
+def ddpm_inference(model: UNetDenoiser, x0, T=80, betas=None):
+    """ddpm_inference(model, x0, T) of conv.ipynb c1:117-125 (beta = linspace(1e-4, 0.02, 100)); the caller supplies
+    the already-degraded image (the reference jpeg-compresses x0 at q20 first)."""
+    if betas is None:
+        betas = np.linspace(1e-4, 0.02, 100, dtype=np.float64).astype(np.float32)
+    return model.p_sample_loop(x0, T, betas)

@@ -458,6 +458,42 @@ def p_sample_loop(eps_model, x, T, betas):
     return x
 
 
+class EpsUnet:
+    """UNetDenoiser.forward (experiments/code/conv.ipynb c0:55-101): eps = net(x, t)."""
+
+    def __init__(self, state):
+        self.p = {k: np.asarray(v, dtype=F32) for k, v in state.items()}
+
+    def _dc(self, name, x):
+        x = np.maximum(conv2d(x, self.p[name + ".conv.0.weight"], self.p[name + ".conv.0.bias"], 1), 0).astype(F32)
+        return np.maximum(conv2d(x, self.p[name + ".conv.2.weight"], self.p[name + ".conv.2.bias"], 1), 0).astype(F32)
+
+    def _up(self, name, x):
+        """nn.ConvTranspose2d(k=2, s=2): out[n,o,2y+i,2x+j] = sum_c x[n,c,y,x] w[c,o,i,j] + b[o]."""
+        w, b = self.p[name + ".weight"], self.p[name + ".bias"]
+        n, c, h, wd = x.shape
+        y = np.einsum("nchw,coij->nohiwj", x, w, optimize=True).reshape(n, w.shape[1], 2 * h, 2 * wd)
+        return (y + b.reshape(1, -1, 1, 1)).astype(F32)
+
+    def __call__(self, x, t):
+        x = np.asarray(x, dtype=F32)
+        tv = np.asarray(t, dtype=F32).reshape(-1, 1)
+        h = np.maximum(tv @ self.p["time_embed.0.weight"].T + self.p["time_embed.0.bias"], 0).astype(F32)
+        temb = (h @ self.p["time_embed.2.weight"].T + self.p["time_embed.2.bias"]).astype(F32)[:, :, None, None]
+        x1 = self._dc("encoder1", x)
+        x2 = self._dc("encoder2", max_pool2(x1))
+        x3 = self._dc("encoder3", max_pool2(x2))
+        z = self._dc("bottleneck", x3) + temb
+        z = self._up("up3", z)
+        z = self._dc("decoder3", np.concatenate([bilinear(x3, z.shape[2], z.shape[3]), z], axis=1))
+        z = self._up("up2", z)
+        z = self._dc("decoder2", np.concatenate([bilinear(x2, z.shape[2], z.shape[3]), z], axis=1))
+        z = self._up("up1", z)
+        z = self._dc("decoder1", np.concatenate([bilinear(x1, z.shape[2], z.shape[3]), z], axis=1))
+        z = conv2d(z, self.p["out_conv.weight"], self.p["out_conv.bias"], 0)
+        return np.tanh(bilinear(z, x.shape[2], x.shape[3])).astype(F32)   # reference hard-codes size=(32, 32)
+
+
 def psnr(a, b):
     """webp_inference.py:691-697: on clamp(x*0.5+0.5, 0, 1); -10 log10(mse + 1e-8)."""
     a01 = np.clip(a * 0.5 + 0.5, 0, 1)

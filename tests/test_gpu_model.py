@@ -193,3 +193,21 @@ def test_sampler_device_codec_equals_host_codec(models, golden):
         a = s.sample(y, q, steps=6, noise=noise, device_codec=False).cpu().numpy()
         b = s.sample(y, q, steps=6, noise=noise, device_codec=True).cpu().numpy()
         assert np.array_equal(a, b), q
+
+
+def test_eps_unet_predict_noise_and_p_sample_loop(golden):
+    """a14: eps-predict UNetDenoiser + ddpm_inference against the reference's own outputs."""
+    import torch
+    from ddpm_image_restoration_amd.model import UNetDenoiser, ddpm_inference
+    g = golden("ddpm_eps")
+    net = UNetDenoiser(device=torch.device("cuda", 0))
+    net.load_state_dict(synth.synth_eps_unet_state(3))
+    eps = net(tt(g["x0"]), torch.tensor([[5.0]])).cpu().numpy()
+    assert np.abs(eps - g["eps_t5"]).max() < 1e-4
+    out = ddpm_inference(net, tt(g["x0"]), T=8, betas=g["betas"]).cpu().numpy()
+    assert np.abs(out - g["out_T8"]).max() < 1e-3
+    # batch > 1 and a second size against the oracle
+    x = (synth.synth_images(3, 64, seed=2) * 0.5 + 0.5).astype(np.float32)
+    ref = O.EpsUnet(synth.synth_eps_unet_state(3))(x, np.array([17.0], np.float32))
+    got = net(tt(x), 17.0).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-4
