@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libddpmir.so")
-SOURCES = ["igemm.hip", "attention.hip", "attention_bf16.hip", "pointwise.hip", "sampler_kernels.hip", "jpeg_sim.hip", "model.hip", "eps_unet.hip", "api.hip", "ops_api.hip"]
+SOURCES = ["igemm.hip", "gemm16.hip", "attention.hip", "attention_bf16.hip", "pointwise.hip", "sampler_kernels.hip", "jpeg_sim.hip", "model.hip", "eps_unet.hip", "api.hip", "ops_api.hip"]
 # MFMA results feed VALU (softmax) directly: keep C/D in VGPRs instead of copying through AGPRs every tile
 VGPR_MFMA = {"attention_bf16.hip", "attention.hip"}
 NO_CONTRACT = {"sampler_kernels.hip"}   # bit-exact uint8 truncation path: no fma contraction

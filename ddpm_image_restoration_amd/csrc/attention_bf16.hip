@@ -131,7 +131,8 @@ constexpr float RESCALE_THR = 20.0f;   // log2 units
 template <int D, int QS, int TS>
 __global__ __launch_bounds__(256) void flash_bf16(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
                                                   const float* __restrict__ Kmax, float* __restrict__ out, int ldo,
-                                                  int N, int NT, int heads, int nqb, int npairs) {
+                                                  int N, int NT, int heads, int nqb, int npairs,
+                                                  __bf16* __restrict__ out16) {
   using G = AttnGeom<D>;
   using SG = StageGeom<D, TS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 stage buffers
@@ -311,21 +312,32 @@ __global__ __launch_bounds__(256) void flash_bf16(const __bf16* __restrict__ Qp,
     const int qr = q0 + 32 * u + lr;
     if (qr < N) {
       float* op = out + ((size_t)b * N + qr) * ldo + head * D;
+      __bf16* op16 = out16 ? out16 + ((size_t)b * N + qr) * (size_t)(heads * D) + head * D : nullptr;
 #pragma unroll
       for (int dt = 0; dt < G::DT; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int dd = dt * 32 + 8 * g + 4 * lh;
-          if (dd < D)
-            *reinterpret_cast<float4*>(op + dd) = make_float4(o[u][dt][4 * g] * inv, o[u][dt][4 * g + 1] * inv,
-                                                              o[u][dt][4 * g + 2] * inv, o[u][dt][4 * g + 3] * inv);
+          if (dd < D) {
+            const float4 v = make_float4(o[u][dt][4 * g] * inv, o[u][dt][4 * g + 1] * inv, o[u][dt][4 * g + 2] * inv,
+                                         o[u][dt][4 * g + 3] * inv);
+            if (op16) {
+              typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+              bf16x4 w;
+              w[0] = (__bf16)v.x; w[1] = (__bf16)v.y; w[2] = (__bf16)v.z; w[3] = (__bf16)v.w;
+              *reinterpret_cast<bf16x4*>(op16 + dd) = w;
+            } else {
+              *reinterpret_cast<float4*>(op + dd) = v;
+            }
+          }
         }
     }
   }
 }
 
 template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT>
-void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* ws, hipStream_t s) {
+void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* ws, hipStream_t s,
+               void* out16) {
   using G = AttnGeom<D>;
   using SG = StageGeom<D, TS>;
   const int NT = (N + 31) / 32;
@@ -345,7 +357,7 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
     attr_set = true;
   }
   hipLaunchKernelGGL((flash_bf16<D, QS, TS>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
-                     out, ldo, N, NT, heads, nqb, BH);
+                     out, ldo, N, NT, heads, nqb, BH, reinterpret_cast<__bf16*>(out16));
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
@@ -376,25 +388,25 @@ size_t attention_bf16_workspace(int B, int N, int C, int heads) {
 }
 
 void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* workspace,
-                           hipStream_t s) {
+                           hipStream_t s, void* out16) {
   static const int var = [] { const char* e = getenv("DDPMIR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // tuning knob
   if (C / heads == 16 && var != 0) {
     switch (var) {
-      case 1: run_flash<16, 1, 16>(qkv, out, ldo, B, N, C, heads, workspace, s); return;
-      case 2: run_flash<16, 1, 8>(qkv, out, ldo, B, N, C, heads, workspace, s); return;
-      case 3: run_flash<16, 1, 4>(qkv, out, ldo, B, N, C, heads, workspace, s); return;
-      case 4: run_flash<16, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s); return;
-      case 5: run_flash<16, 2, 8>(qkv, out, ldo, B, N, C, heads, workspace, s); return;
-      case 6: run_flash<16, 2, 4>(qkv, out, ldo, B, N, C, heads, workspace, s); return;
+      case 1: run_flash<16, 1, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 2: run_flash<16, 1, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 3: run_flash<16, 1, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 4: run_flash<16, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 5: run_flash<16, 2, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 6: run_flash<16, 2, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       default: break;
     }
   }
   switch (C / heads) {
-    case 8: run_flash<8, 1>(qkv, out, ldo, B, N, C, heads, workspace, s); break;
-    case 16: run_flash<16, 1>(qkv, out, ldo, B, N, C, heads, workspace, s); break;
-    case 32: run_flash<32, 1>(qkv, out, ldo, B, N, C, heads, workspace, s); break;
-    case 64: run_flash<64, 1>(qkv, out, ldo, B, N, C, heads, workspace, s); break;
-    case 128: run_flash<128, 1>(qkv, out, ldo, B, N, C, heads, workspace, s); break;
+    case 8: run_flash<8, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
+    case 16: run_flash<16, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
+    case 32: run_flash<32, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
+    case 64: run_flash<64, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
+    case 128: run_flash<128, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     default: throw std::runtime_error("attention_bf16: unsupported head dim");
   }
 }

@@ -1,0 +1,305 @@
+// bf16 implicit GEMM with BOTH operands streamed by LDS-DMA (global_load_lds_dwordx4), gfx950.
+//
+//   out[m][n] = epi( sum_{tap,c} A16[pixel(m)+tap][c] * W16[tap][n][c] )
+//
+// A16 is a bf16 NHWC tensor that already contains what the GEMM consumes (normalised / activated / masked by
+// the producing kernel), so nothing has to pass through VGPRs on the way in: every wave issues 16-byte-per-lane
+// direct-to-LDS loads for a 3-stage ring and only waits with a counted vmcnt -- the loads of two K chunks stay
+// in flight across the barrier while the MFMAs of the current chunk run.
+//
+// LDS image per stage: A [128 rows][64 k] bf16, B [32*NT rows][64 k] bf16, 128-byte rows, no padding.
+// A DMA wave-instruction writes 64 lanes x 16 B linearly (8 rows), so the bank-conflict fix is an XOR swizzle on
+// the SOURCE address: LDS chunk p of row r holds global chunk p ^ ((r>>1)&7); the MFMA operand read applies the
+// same XOR (rule: linear destination + permuted source + permuted read).  Rows outside the image (3x3 halo),
+// rows past M / Cout and channel chunks past Cin are fetched from a 16-byte zero page.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace ddpmir {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+namespace {
+
+constexpr int BM = 128, BK = 64, STAGES = 3, ROWB = BK * 2;   // 128-byte LDS rows
+
+template <int NT>
+__global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = NT * 32 * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int LOADS = 4 + NT;                       // DMA instructions per thread per stage
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = p.B * p.H * p.W, HW = p.H * p.W;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * (NT * 32);
+  const int nck = (p.Cin + BK - 1) / BK;
+  const int nit_all = p.taps * nck;
+  const int nsplit = gridDim.z, sk = blockIdx.z;
+  const int it0 = (int)((long long)nit_all * sk / nsplit), it1 = (int)((long long)nit_all * (sk + 1) / nsplit);
+  const int nit = it1 - it0;
+  const __bf16* A16 = reinterpret_cast<const __bf16*>(p.A16);
+  const __bf16* W16 = reinterpret_cast<const __bf16*>(p.Wt16);
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zero16);
+  const unsigned lds0 = (unsigned)(size_t)smem;
+
+  // per-thread DMA slots: A slot j covers LDS row (j*256 + tid)/8, chunk position (tid & 7)
+  int a_y[4], a_x[4];
+  bool a_ok[4];
+  size_t a_off[4];
+  int a_chunk[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (j * 256 + tid) >> 3, pos = tid & 7;
+    const int m = m0 + row;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int b = mm / HW, rem = mm - b * HW;
+    a_y[j] = rem / p.W; a_x[j] = rem - a_y[j] * p.W;
+    a_ok[j] = ok;
+    a_off[j] = (size_t)mm * p.lda16;
+    a_chunk[j] = pos ^ ((row >> 1) & 7);              // which 8-channel chunk of the row this slot holds
+  }
+  int b_n[NT], b_chunk[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int row = (j * 256 + tid) >> 3, pos = tid & 7;
+    b_n[j] = n0 + row;
+    b_chunk[j] = pos ^ ((row >> 1) & 7);
+  }
+
+  auto issue = [&](int itl) {
+    const int it = it0 + itl;
+    const int tap = it / nck;
+    const int c0 = (it - tap * nck) * BK;
+    int dy = 0, dx = 0;
+    if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+    const unsigned sbase = lds0 + (itl % STAGES) * STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + 8 * a_chunk[j];
+      const bool ok = a_ok[j] && c < p.Cin && (unsigned)(a_y[j] + dy) < (unsigned)p.H && (unsigned)(a_x[j] + dx) < (unsigned)p.W;
+      const void* g = ok ? (const void*)(A16 + a_off[j] + (ptrdiff_t)(dy * p.W + dx) * p.lda16 + c) : (const void*)zero;
+      __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sbase + (j * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int c = c0 + 8 * b_chunk[j];
+      const bool ok = b_n[j] < p.Cout && c < p.Cin;
+      const void* g = ok ? (const void*)(W16 + ((size_t)tap * p.Cout + b_n[j]) * p.Cin + c) : (const void*)zero;
+      __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sbase + A_BYTES + (j * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  const int arow = wave * 32 + lr;
+  const int a_key = (arow >> 1) & 7, b_key = (lr >> 1) & 7;      // b rows: nt*32 + lr -> (row>>1)&7 == (lr>>1)&7
+
+  if (nit > 0) issue(0);
+  if (nit > 1) issue(1);
+  for (int it = 0; it < nit; ++it) {
+    // stage `it` has landed once at most one younger stage of THIS wave is still in flight; the barrier extends
+    // that to every wave's share and also retires everybody's reads of the buffer that is refilled next
+    if (it + 1 < nit) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < nit) issue(it + 2);
+    const unsigned char* st = smem + (it % STAGES) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(st + arow * ROWB + (((2 * ks + lh) ^ a_key) << 4));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(st + A_BYTES + (nt * 32 + lr) * ROWB + (((2 * ks + lh) ^ b_key) << 4));
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[nt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------ epilogue
+  const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE;
+  const bool atomic = nsplit > 1;
+  const bool lead = sk == 0;
+  if (atomic) {
+    // split-K partial sums (linear epilogue only): 256-byte row segments per wave instruction
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= M) continue;
+      const int b = p.tb ? m / HW : 0;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + nt * 32 + lr;
+        if (n >= p.Cout) continue;
+        float v = acc[nt][r];
+        if (lead) {
+          if (p.bias) v += p.bias[n];
+          if (p.tb) v += p.tb[(size_t)b * p.ldtb + n];
+          if (p.res && p.res != p.out) v += p.res[(size_t)m * p.ldres + n];
+        }
+        atomicAdd(&p.out[(size_t)m * p.ldo + n], v);
+      }
+    }
+    return;
+  }
+  // coalesced: accumulators -> wave-private LDS tile -> 16-byte row-contiguous accesses
+  constexpr int BN = NT * 32, BNP = BN + 4;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                         // all waves are done reading the stage buffers
+  float* ct = reinterpret_cast<float*>(smem) + wave * 32 * BNP;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + nt * 32 + lr] = acc[nt][r];
+  constexpr int L4 = BN / 4, RPP = 64 / L4;
+  const int c4 = lane % L4, rsub = lane / L4;
+  const int n = n0 + 4 * c4;
+  if (n >= p.Cout) return;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+  __bf16* out16 = reinterpret_cast<__bf16*>(p.out16);
+#pragma unroll 4
+  for (int pass = 0; pass < 32 / RPP; ++pass) {
+    const int row = pass * RPP + rsub;
+    const int m = m0 + wave * 32 + row;
+    if (m >= M) continue;
+    float4 v = *reinterpret_cast<const float4*>(ct + row * BNP + 4 * c4);
+    int b = 0, y = 0, x = 0;
+    if (need_pos) {
+      b = m / HW;
+      const int rem = m - b * HW;
+      y = rem / p.W;
+      x = rem - y * p.W;
+    }
+    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+    if (p.tb) { float4 t = *reinterpret_cast<const float4*>(p.tb + (size_t)b * p.ldtb + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (p.epi_act != ACT_NONE) { v.x = act_apply(v.x, p.epi_act); v.y = act_apply(v.y, p.epi_act); v.z = act_apply(v.z, p.epi_act); v.w = act_apply(v.w, p.epi_act); }
+    if (p.mul) { float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + n); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+    if (p.rowscale) { const float rs = p.rowscale[b]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+    if (p.epi_mask != MASK_NONE) {
+      const bool lowp = is_low_freq(y, x, p.H, p.W, p.bs, p.low);
+      const bool keep = (p.epi_mask == MASK_LOW) ? lowp : !lowp;
+      if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + n) = v;
+    if (out16) {
+      bf16x4 o;
+      o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+      *reinterpret_cast<bf16x4*>(out16 + (size_t)m * p.ldo16 + n) = o;
+    }
+  }
+}
+
+__global__ void zero_rows16_k(float* out, int ldo, int64_t M, int C4) {
+  const int64_t total = M * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t m = i / C4;
+    int c4 = (int)(i - m * C4);
+    *reinterpret_cast<float4*>(out + m * ldo + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// fp32 [M][ldx] -> bf16 [M][ld16] with the GroupNorm affine + activation of the consuming conv applied once
+// (x*scale[b][c] + shift[b][c], then act); optionally also a raw bf16 copy (input of the 1x1 shortcut conv).
+__global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C, int Cs, const float* __restrict__ scale,
+                             const float* __restrict__ shift, int act, __bf16* __restrict__ out, int ld16,
+                             __bf16* __restrict__ raw, int ldraw, int64_t M) {
+  const int C8 = (C + 7) / 8;
+  const int64_t total = M * C8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / C8;
+    const int c = (int)(i - m * C8) * 8;
+    const int b = (int)(m / HW);
+    float v[8], r[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f), s = t, f = t;
+      const bool ok = c + 4 * h < C;                     // C is a multiple of 4
+      if (ok) {
+        t = *reinterpret_cast<const float4*>(x + m * ldx + c + 4 * h);
+        if (scale) {
+          s = *reinterpret_cast<const float4*>(scale + (size_t)b * Cs + c + 4 * h);
+          f = *reinterpret_cast<const float4*>(shift + (size_t)b * Cs + c + 4 * h);
+        } else {
+          s = make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+      }
+      r[4 * h] = t.x; r[4 * h + 1] = t.y; r[4 * h + 2] = t.z; r[4 * h + 3] = t.w;
+      v[4 * h] = ok ? act_apply(fmaf(t.x, s.x, f.x), act) : 0.f;
+      v[4 * h + 1] = ok ? act_apply(fmaf(t.y, s.y, f.y), act) : 0.f;
+      v[4 * h + 2] = ok ? act_apply(fmaf(t.z, s.z, f.z), act) : 0.f;
+      v[4 * h + 3] = ok ? act_apply(fmaf(t.w, s.w, f.w), act) : 0.f;
+    }
+    bf16x8 o, q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o[j] = (__bf16)v[j]; q[j] = (__bf16)r[j]; }
+    if (out) *reinterpret_cast<bf16x8*>(out + m * ld16 + c) = o;
+    if (raw) *reinterpret_cast<bf16x8*>(raw + m * ldraw + c) = q;
+  }
+}
+
+template <int NT>
+void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
+  constexpr int STAGE = (BM + NT * 32) * ROWB;
+  constexpr int EPI = 4 * 32 * (NT * 32 + 4) * 4;
+  constexpr int LDS = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
+  static bool attr = false;
+  if (!attr) {
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<NT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr = true;
+  }
+  const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
+  const int nit = p.taps * cdiv(p.Cin, BK);
+  int nsplit = 1;
+  const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && !p.out16 && p.out &&
+                      (!p.res || p.res != p.out || p.ldres == p.ldo);
+  if (linear && gx * gy < 256 && nit >= 8) {
+    nsplit = std::min(std::min(16, nit / 4), cdiv(512, gx * gy));
+    if (nsplit < 1) nsplit = 1;
+  }
+  if (nsplit > 1 && !(p.res && p.res == p.out))
+    hipLaunchKernelGGL(zero_rows16_k, dim3((unsigned)std::min<int64_t>(cdiv64(M * (p.Cout / 4), 256), 2048)), dim3(256), 0,
+                       stream, p.out, p.ldo, M, p.Cout / 4);
+  hipLaunchKernelGGL(gemm16_kernel<NT>, dim3(gx, gy, nsplit), dim3(256), LDS, stream, p);
+}
+
+}  // namespace
+
+bool gemm16_supported(const IGemm& p) {
+  return p.A16 && p.Wt16 && p.zero16 && (p.Cin % 8) == 0 && (p.lda16 % 8) == 0 && (p.Cout % 4) == 0 &&
+         p.store == STORE_NHWC && p.pro_mask == MASK_NONE && !p.scale && p.pro_act == ACT_NONE;
+}
+
+void launch_gemm16(const IGemm& p, hipStream_t stream) {
+  if (!gemm16_supported(p)) throw std::runtime_error("gemm16: unsupported operand layout");
+  const int64_t M = (int64_t)p.B * p.H * p.W;
+  if (M <= 0 || p.Cout <= 0) return;
+  if (p.Cout <= 32) launch_nt<1>(p, M, stream);
+  else if (p.Cout <= 64) launch_nt<2>(p, M, stream);
+  else launch_nt<4>(p, M, stream);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_gn_apply16(const float* x, int ldx, int B, int HW, int C, const float* scale, const float* shift, int act,
+                       void* out16, int ld16, void* raw16, int ldraw, hipStream_t s) {
+  const int64_t M = (int64_t)B * HW;
+  const int64_t total = M * ((C + 7) / 8);
+  int64_t g = (total + 255) / 256;
+  g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+  hipLaunchKernelGGL(gn_apply16_k, dim3((unsigned)g), dim3(256), 0, s, x, ldx, HW, C, round_up(C, 4), scale, shift, act,
+                     reinterpret_cast<__bf16*>(out16), ld16, reinterpret_cast<__bf16*>(raw16), ldraw, M);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace ddpmir

@@ -30,9 +30,18 @@ struct IGemm {
   const float* res = nullptr; int ldres = 0;
   // output
   float* out = nullptr; int ldo = 0; int store = STORE_NHWC;
+  // DMA-streamed bf16 path (gemm16.hip): A already holds what the GEMM consumes, as bf16 [B*H*W][lda16]
+  const void* A16 = nullptr; int lda16 = 0;
+  const void* zero16 = nullptr;               // >= 16 bytes of zeros in device memory (halo / tail source)
+  void* out16 = nullptr; int ldo16 = 0;       // optional bf16 copy of the epilogue result (out may then be null)
   int dbg = 0;   // timing experiments only: 1 skip A loads, 2 skip B loads, 4 skip MFMA, 8 skip stores, 16 skip LDS writes
 };
 void launch_igemm(const IGemm& p, hipStream_t stream);
+bool gemm16_supported(const IGemm& p);
+void launch_gemm16(const IGemm& p, hipStream_t stream);
+// fp32 -> bf16 with GroupNorm affine + activation applied once for the consuming conv; optional raw bf16 copy
+void launch_gn_apply16(const float* x, int ldx, int B, int HW, int C, const float* scale, const float* shift, int act,
+                       void* out16, int ld16, void* raw16, int ldraw, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------ attention
 // softmax(Q K^T / sqrt(d)) V per (batch, head); qkv is [B][N][3C] (q | k | v, heads contiguous in C),
@@ -43,8 +52,9 @@ void launch_attention(const float* qkv, float* out, int ldo, int B, int N, int C
 // images in `workspace` (attention_bf16_workspace() bytes), softmax statistics and accumulators are fp32.
 bool attention_bf16_supported(int N, int C, int heads);
 size_t attention_bf16_workspace(int B, int N, int C, int heads);
+// out16 != nullptr: the result is written as bf16 [B][N][C] there instead of fp32 `out`
 void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* workspace,
-                           hipStream_t stream);
+                           hipStream_t stream, void* out16 = nullptr);
 
 // ------------------------------------------------------------------------------------------------ pointwise
 // GroupNorm statistics -> per-(b,c) scale/shift so that norm(x) = x*scale + shift (eps 1e-5, biased var).
@@ -63,8 +73,10 @@ void launch_adaptive_avgpool(const float* in, int ldi, float* out, int ldo, int 
 
 // blockwise Y = T X T^T (block bs in {4,8}); mats: one [bs][bs] matrix (per_channel=0) or [C][bs][bs].
 // out = mix_in * x + mix_t * Y   (mix_in=0,mix_t=1: plain transform; head: 1, 0.1)
+// low16/high16 (optional): bf16 copies of the result masked to the low / high in-block frequencies [B*H*W][C]
 void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int bs,
-                            const float* mats, int per_channel, float mix_in, float mix_t, hipStream_t s);
+                            const float* mats, int per_channel, float mix_in, float mix_t, hipStream_t s,
+                            void* low16 = nullptr, void* high16 = nullptr, int low = 0);
 
 // out = a * b * c * d (+ base)   elementwise over [M][C] with per-tensor strides; null pointers are skipped
 void launch_mul4_add(const float* base, int ldb, const float* a, int lda, const float* b, int ldb2, const float* c,

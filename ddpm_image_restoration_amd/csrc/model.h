@@ -113,6 +113,10 @@ class Context {
     float *hA = nullptr, *hB = nullptr, *qkv = nullptr, *att = nullptr, *xd = nullptr, *hid = nullptr, *S = nullptr;
     float *xt = nullptr, *avg = nullptr, *col = nullptr, *edge = nullptr, *pool = nullptr, *pg1 = nullptr, *pg2 = nullptr;
     unsigned char* attn_ws = nullptr;
+    // bf16 operand tensors of the DMA-streamed GEMM path (dtype = bf16, DCT families)
+    unsigned short *a16 = nullptr, *x16 = nullptr, *hB16 = nullptr, *att16 = nullptr, *xdl16 = nullptr, *xdh16 = nullptr,
+                   *hid16 = nullptr, *S16 = nullptr;
+    unsigned char* zero16 = nullptr;
     double* gn_partial = nullptr;
     float *sc1 = nullptr, *sh1 = nullptr, *sc2 = nullptr, *sh2 = nullptr;
     float *hidden = nullptr, *temb = nullptr, *tproj = nullptr;
@@ -132,6 +136,9 @@ class Context {
 
   void forward(const float* x, const float* t, const float* cl, float* out, hipStream_t s);
   void run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
+  void run_block16(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
+  void conv16(const ConvW& cw, IGemm p, hipStream_t s);
+  bool use_gemm16() const { return cfg.dtype == DDPMIR_BF16 && cfg.arch != DDPMIR_ARCH_AVIF; }
   void freq_dct(const BlockW& bw, int H, int W, hipStream_t s);
   void freq_avif(const BlockW& bw, int H, int W, hipStream_t s);
   void avif_transform(const AvifTransformW& at, const float* x, int ldx, int C, int H, int W, float* T, float* tmp,

@@ -255,6 +255,14 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
         ws = std::max(ws, attention_bf16_workspace(B, (int)hw(d.level), d.cout, k.heads));
     p.attn_ws = a.take<unsigned char>(ws + 256);
   }
+  if (use_gemm16()) {
+    size_t ma = 0;
+    for (auto& d : kBlocks) ma = std::max(ma, (size_t)B * hw(d.level) * (size_t)std::max(round_up(d.cin, 8), d.cout));
+    p.a16 = a.take<unsigned short>(ma); p.x16 = a.take<unsigned short>(ma);
+    p.hB16 = a.take<unsigned short>(mc); p.att16 = a.take<unsigned short>(mc); p.xdl16 = a.take<unsigned short>(mc);
+    p.xdh16 = a.take<unsigned short>(mc); p.hid16 = a.take<unsigned short>(mc); p.S16 = a.take<unsigned short>(mc);
+    p.zero16 = a.take<unsigned char>(256);
+  }
   int max_splits = gn_splits(H * W, 64);
   p.gn_partial = a.take<double>((size_t)B * 8 * max_splits * 2 + 64);
   p.sc1 = a.take<float>((size_t)B * 1024); p.sh1 = a.take<float>((size_t)B * 1024);
@@ -438,8 +446,88 @@ void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
   launch_mul4_add(p.hB, C, p.xt, C, p.avg, C, p.col, C, p.edge, C, p.S, C, M, C, s);
 }
 
+void Context::conv16(const ConvW& cw, IGemm p, hipStream_t s) {
+  p.Wt = cw.w; p.Wt16 = cw.w16; p.bias = cw.b; p.Cout = cw.cout; p.Cin = cw.cinp; p.taps = cw.taps;
+  p.zero16 = plan_.zero16;
+  if (gemm16_supported(p)) launch_gemm16(p, s);
+  else throw std::logic_error("conv16: operand layout not supported by the DMA GEMM");
+}
+
+// bf16 mode, DCT families: every GEMM input is a bf16 tensor written once by its producer (GroupNorm-apply pass,
+// previous GEMM epilogue, attention, DCT kernel), so both GEMM operands stream by LDS-DMA (gemm16.hip).
+// The fp32 tensors that carry the residual stream and the GroupNorm statistics stay fp32.
+void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest,
+                          hipStream_t s) {
+  Plan& p = plan_;
+  const int B = p.B, C = bw.cout, HW = H * W;
+  const int cin8 = round_up(bw.cin, 8);
+  IGemm g; g.B = B; g.H = H; g.W = W; g.bs = k.dct_block; g.low = k.low_size;
+  // norm1 -> conv1 (+ bias + time projection)
+  launch_gn_scale_shift(in, ldin, B, HW, bw.cin, gn_groups(bw.cin), bw.n1g, bw.n1b, p.gn_partial, p.sc1, p.sh1, s);
+  if (bw.cinp % 8 == 0) {
+    launch_gn_apply16(in, ldin, B, HW, bw.cin, p.sc1, p.sh1, ACT_NONE, p.a16, cin8, bw.has_shortcut ? p.x16 : nullptr,
+                      cin8, s);
+    IGemm c1 = g; c1.A16 = p.a16; c1.lda16 = cin8; c1.tb = p.tproj + bw.tproj_off; c1.ldtb = nt_total_;
+    c1.out = p.hA; c1.ldo = C;
+    conv16(bw.conv1, c1, s);
+  } else {   // 3-channel image input: register-staged kernel
+    IGemm c1 = g; c1.A = in; c1.lda = ldin; c1.scale = p.sc1; c1.shift = p.sh1;
+    c1.tb = p.tproj + bw.tproj_off; c1.ldtb = nt_total_; c1.out = p.hA; c1.ldo = C;
+    conv(bw.conv1, c1, s);
+  }
+  // norm2 -> GELU -> conv2 ; hB also as bf16 for the qkv projection
+  launch_gn_scale_shift(p.hA, C, B, HW, C, gn_groups(C), bw.n2g, bw.n2b, p.gn_partial, p.sc2, p.sh2, s);
+  launch_gn_apply16(p.hA, C, B, HW, C, p.sc2, p.sh2, ACT_GELU, p.a16, C, nullptr, 0, s);
+  const bool attn = bw.level >= cfg.attn_min_level;
+  IGemm c2 = g; c2.A16 = p.a16; c2.lda16 = C; c2.out = p.hB; c2.ldo = C;
+  if (attn) { c2.out16 = p.hB16; c2.ldo16 = C; }
+  conv16(bw.conv2, c2, s);
+  if (attn) {
+    IGemm q = g; q.A16 = p.hB16; q.lda16 = C; q.out = p.qkv; q.ldo = 3 * C;
+    conv16(bw.in_proj, q, s);
+    const double nn = (double)HW;
+    prof_begin(bw.level == 0 ? PROF_ATTN_L0 : PROF_ATTN, 4.0 * nn * nn * C * B, s);
+    if (attention_bf16_supported(HW, C, k.heads)) {
+      launch_attention_bf16(p.qkv, p.att, C, B, HW, C, k.heads, p.attn_ws, s, p.att16);
+    } else {
+      launch_attention(p.qkv, p.att, C, B, HW, C, k.heads, s);
+      launch_gn_apply16(p.att, C, B, HW, C, nullptr, nullptr, ACT_NONE, p.att16, C, nullptr, 0, s);
+    }
+    prof_end(s);
+    IGemm o = g; o.A16 = p.att16; o.lda16 = C; o.res = p.hB; o.ldres = C; o.out = p.hB; o.ldo = C;
+    conv16(bw.out_proj, o, s);
+  }
+  // frequency block: DCT -> masked bf16 operands -> gates -> S (bf16 only, it feeds conv_out alone)
+  launch_block_transform(p.hB, C, p.xd, C, B, H, W, C, k.dct_block, bw.dct, 0, 0.f, 1.f, s, p.xdl16, p.xdh16, k.low_size);
+  IGemm a = g; a.A16 = p.xdl16; a.lda16 = C; a.epi_act = ACT_LRELU; a.out16 = p.hid16; a.ldo16 = C / 2;
+  conv16(bw.low0, a, s);
+  IGemm b2 = g; b2.A16 = p.hid16; b2.lda16 = C / 2; b2.epi_act = ACT_SIGMOID; b2.mul = p.xd; b2.ldmul = C;
+  b2.epi_mask = MASK_LOW; b2.res = p.hB; b2.ldres = C; b2.out = p.S; b2.ldo = C;
+  conv16(bw.low2, b2, s);
+  IGemm c = a; c.A16 = p.xdh16;
+  conv16(bw.high0, c, s);
+  IGemm d = b2; d.epi_mask = MASK_HIGH; d.rowscale = p.boost; d.res = p.S; d.ldres = C; d.out = nullptr;
+  d.out16 = p.S16; d.ldo16 = C;
+  conv16(bw.high2, d, s);
+  // shortcut + conv_out
+  const float* res = in; int ldres = ldin;
+  if (bw.has_shortcut) {
+    if (bw.cinp % 8 == 0) {
+      IGemm sc = g; sc.A16 = p.x16; sc.lda16 = cin8; sc.out = dest; sc.ldo = lddest;
+      conv16(bw.shortcut, sc, s);
+    } else {
+      IGemm sc = g; sc.A = in; sc.lda = ldin; sc.out = dest; sc.ldo = lddest;
+      conv(bw.shortcut, sc, s);
+    }
+    res = dest; ldres = lddest;
+  }
+  IGemm co = g; co.A16 = p.S16; co.lda16 = C; co.res = res; co.ldres = ldres; co.out = dest; co.ldo = lddest;
+  conv16(bw.conv_out, co, s);
+}
+
 void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest,
                         hipStream_t s) {
+  if (use_gemm16()) { run_block16(bw, in, ldin, H, W, dest, lddest, s); return; }
   Plan& p = plan_;
   const int B = p.B, C = bw.cout;
   IGemm g; g.B = B; g.H = H; g.W = W;

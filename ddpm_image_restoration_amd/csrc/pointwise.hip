@@ -186,7 +186,8 @@ __global__ void adaptive_avgpool_k(const float* __restrict__ in, int ldi, float*
 template <int BS>
 __global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_k(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B,
                                   int H, int W, int C, const float* __restrict__ mats, int per_channel,
-                                  float mix_in, float mix_t) {
+                                  float mix_in, float mix_t, __bf16* __restrict__ low16, __bf16* __restrict__ high16,
+                                  int low) {
   __shared__ float Ts[BS * BS];
   if (!per_channel) {
     for (int i = threadIdx.x; i < BS * BS; i += blockDim.x) Ts[i] = mats[i];
@@ -238,7 +239,16 @@ __global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_k(const f
         float a = 0.f;
 #pragma unroll
         for (int k = 0; k < BS; ++k) a = fmaf(tmp[u][k], tr[k], a);
-        if (y < H && x < W) out[(((size_t)b * H + y) * W + x) * ldo + c] = mix_in * X[u][v] + mix_t * a;
+        if (y < H && x < W) {
+          const size_t o = (((size_t)b * H + y) * W + x);
+          const float val = mix_in * X[u][v] + mix_t * a;
+          out[o * ldo + c] = val;
+          if (low16) {   // pre-masked bf16 operands of the low / high frequency gate GEMMs
+            const bool lowp = is_low_freq(y, x, H, W, BS, low);
+            low16[o * C + c] = (__bf16)(lowp ? val : 0.f);
+            high16[o * C + c] = (__bf16)(lowp ? 0.f : val);
+          }
+        }
       }
     }
   }
@@ -389,14 +399,17 @@ void launch_adaptive_avgpool(const float* in, int ldi, float* out, int ldo, int 
 }
 
 void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int bs,
-                            const float* mats, int per_channel, float mix_in, float mix_t, hipStream_t s) {
+                            const float* mats, int per_channel, float mix_in, float mix_t, hipStream_t s,
+                            void* low16, void* high16, int low) {
   int64_t total = (int64_t)B * cdiv(H, bs) * cdiv(W, bs) * C;
+  __bf16* l16 = reinterpret_cast<__bf16*>(low16);
+  __bf16* h16 = reinterpret_cast<__bf16*>(high16);
   if (bs == 4)
     hipLaunchKernelGGL(block_transform_k<4>, dim3(grid_for(total)), dim3(256), 0, s, in, ldi, out, ldo, B, H, W, C,
-                       mats, per_channel, mix_in, mix_t);
+                       mats, per_channel, mix_in, mix_t, l16, h16, low);
   else if (bs == 8)
     hipLaunchKernelGGL(block_transform_k<8>, dim3(grid_for(total, 128)), dim3(128), 0, s, in, ldi, out, ldo, B, H, W,
-                       C, mats, per_channel, mix_in, mix_t);
+                       C, mats, per_channel, mix_in, mix_t, l16, h16, low);
   else
     throw std::runtime_error("block transform: block size must be 4 or 8");
   DDPMIR_HIP_CHECK(hipGetLastError());

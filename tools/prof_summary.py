@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(t)))
 n_fwd = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
-    k = r["Kernel_Name"].split("(")[0].replace("void ddpmir::(anonymous namespace)::", "").replace("ddpmir::(anonymous namespace)::", "")
+    k = r["Kernel_Name"].replace("void ", "").replace("ddpmir::(anonymous namespace)::", "").split("(")[0]
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     agg[k][0] += 1; agg[k][1] += us
 tot = sum(v[1] for v in agg.values())
