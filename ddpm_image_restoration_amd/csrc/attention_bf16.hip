@@ -229,6 +229,48 @@ __global__ __launch_bounds__(256) void flash_bf16(const __bf16* __restrict__ Qp,
     if (st + 1 < nstages) gload(st + 1);
     const unsigned char* sb = lds + buf * SG::STAGE_BYTES;
     const int tiles_here = min(TS, NT - st * TS);
+    // Stage-level bound: if |q| * max_k|k| over the WHOLE stage cannot exceed the running max by the threshold,
+    // no tile of the stage can trigger a rescale -> run the stage without any per-tile max / vote / branch.
+    float smax = 0.f;
+#pragma unroll
+    for (int t = 0; t < TS; ++t) smax = fmaxf(smax, kmax_lds[buf * TS + t]);
+    bool fast = st > 0 && !(st == nstages - 1 && (N & 31) != 0);
+#pragma unroll
+    for (int u = 0; u < QS; ++u) fast = fast && !__any(fmaf(qn[u], smax, -m_run[u]) > RESCALE_THR);
+    if (fast) {
+      for (int t = 0; t < tiles_here; ++t) {
+        const unsigned char* tb = sb + t * G::TILE_BYTES;
+        bf16x8 kf[G::KC];
+#pragma unroll
+        for (int c = 0; c < G::KC; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(tb + c * 1024 + lane * 16);
+        bf16x8 vf[G::DT][2];
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            vf[dt][s] = *reinterpret_cast<const bf16x8*>(tb + G::KT_BYTES + ((dt * 2 + s) * 2 + lh) * (G::RV * 16) + vrow * 16);
+#pragma unroll
+        for (int u = 0; u < QS; ++u) {
+          f32x16 s = negm[u];
+#pragma unroll
+          for (int c = 0; c < G::KC; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[u][c], s, 0, 0, 0);
+          bf16x8 pb[2];
+          float ps = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float p = __builtin_amdgcn_exp2f(s[r]);
+            if (!G::ONES) ps += p;
+            pb[r >> 3][r & 7] = (__bf16)p;
+          }
+          if (!G::ONES) lsum[u] += ps;
+#pragma unroll
+          for (int dt = 0; dt < G::DT; ++dt) {
+            o[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], pb[0], o[u][dt], 0, 0, 0);
+            o[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][1], pb[1], o[u][dt], 0, 0, 0);
+          }
+        }
+      }
+    } else
     for (int t = 0; t < tiles_here; ++t) {
       const int kt = st * TS + t;
       const unsigned char* tb = sb + t * G::TILE_BYTES;
