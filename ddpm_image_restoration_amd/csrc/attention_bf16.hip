@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void pack_qkv_bf16(const float* __restrict__ q
 // ------------------------------------------------------------------------------------------------ flash
 constexpr float RESCALE_THR = 20.0f;   // log2 units
 
-template <int D, int QS, int TS>
-__global__ __launch_bounds__(256) void flash_bf16(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
+template <int D, int QS, int TS, int WPS = 0>
+__global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
                                                   const float* __restrict__ Kmax, float* __restrict__ out, int ldo,
                                                   int N, int NT, int heads, int nqb, int npairs,
                                                   __bf16* __restrict__ out16) {
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void flash_bf16(const __bf16* __restrict__ Qp,
   }
 }
 
-template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT>
+template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT, int WPS = 0>
 void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* ws, hipStream_t s,
                void* out16) {
   using G = AttnGeom<D>;
@@ -394,11 +394,11 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
   const int nqb = (N + 128 * QS - 1) / (128 * QS);
   static bool attr_set = false;
   if (!attr_set) {
-    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16<D, QS, TS>),
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16<D, QS, TS, WPS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SG::STAGE_BYTES + 2 * TS * 4));
     attr_set = true;
   }
-  hipLaunchKernelGGL((flash_bf16<D, QS, TS>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
+  hipLaunchKernelGGL((flash_bf16<D, QS, TS, WPS>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
                      out, ldo, N, NT, heads, nqb, BH, reinterpret_cast<__bf16*>(out16));
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
@@ -440,12 +440,17 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
       case 4: run_flash<16, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 5: run_flash<16, 2, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 6: run_flash<16, 2, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 7: run_flash<16, 1, 8, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 8: run_flash<16, 1, 4, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 9: run_flash<16, 2, 8, 3>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       default: break;
     }
   }
   switch (C / heads) {
-    case 8: run_flash<8, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
-    case 16: run_flash<16, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
+    // head_dim <= 16 is bound by v_exp issue: two query sub-tiles per wave share every K/V fragment read and give
+    // the scheduler two independent exp/pack/PV chains (A/B on one device: 7.92 vs 8.49 ms at N = 65 536)
+    case 8: run_flash<8, 2>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
+    case 16: run_flash<16, 2>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     case 32: run_flash<32, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     case 64: run_flash<64, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     case 128: run_flash<128, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
