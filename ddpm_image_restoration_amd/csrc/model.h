@@ -144,8 +144,10 @@ class Context {
   void avif_transform(const AvifTransformW& at, const float* x, int ldx, int C, int H, int W, float* T, float* tmp,
                       float* out, int ldo, const float* rowscale, const float* res, int ldres, hipStream_t s);
   void conv(const ConvW& cw, IGemm p, hipStream_t s);
-  void phase_fix(float* x, int B, int H, int W, double alpha, hipStream_t s);   // uses cached unit phase of y
-  void phase_prepare(const float* y, int B, int H, int W, hipStream_t s);
+  void phase_fix(float* x, int B, int H, int W, double alpha, hipStream_t s, size_t off);   // uses cached unit phase of y
+  void phase_prepare(const float* y, int B, int H, int W, hipStream_t s, size_t off);
+  int fb_ = 0;                      // batch of the forward being enqueued (<= plan_.B; micro-batch lanes)
+  hipEvent_t lane_ev_[2] = {nullptr, nullptr};
 
   // ---- HIP-event profiling of kernel classes
   struct ProfSpan { hipEvent_t a, b; int cls; double flops; };

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -43,6 +44,8 @@ Context::Context(const ddpmir_config& c) : cfg(c), k(consts_for(c.arch)) {
   DDPMIR_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   DDPMIR_HIP_CHECK(hipEventCreate(&ev0_));
   DDPMIR_HIP_CHECK(hipEventCreate(&ev1_));
+  DDPMIR_HIP_CHECK(hipEventCreateWithFlags(&lane_ev_[0], hipEventDisableTiming));
+  DDPMIR_HIP_CHECK(hipEventCreateWithFlags(&lane_ev_[1], hipEventDisableTiming));
 }
 
 Context::~Context() {
@@ -53,6 +56,7 @@ Context::~Context() {
   if (pin_out_) (void)hipHostFree(pin_out_);
   for (auto& sp : prof_spans_) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (auto e : prof_pool_) (void)hipEventDestroy(e);
+  for (auto e : lane_ev_) if (e) (void)hipEventDestroy(e);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -303,6 +307,7 @@ void Context::ensure_plan(int B, int H, int W) {
   Arena a; a.base = base;
   layout_plan(a, B, H, W);
   plan_.base = base; plan_.bytes = bytes; plan_.B = B; plan_.H = H; plan_.W = W;
+  fb_ = B;
   // DFT twiddles (double precision on the host, rounded once)
   auto tw = [&](int n, float* dc, float* ds) {
     std::vector<float> c(n), s(n);
@@ -384,7 +389,7 @@ void Context::conv(const ConvW& cw, IGemm p, hipStream_t s) {
 // WebP/JPEG frequency block (webp_inference.py:231-270).  In: plan_.hB.  Out: plan_.S = x + ga*low + gb*high.
 void Context::freq_dct(const BlockW& bw, int H, int W, hipStream_t s) {
   Plan& p = plan_;
-  const int B = p.B, C = bw.cout;
+  const int B = fb_, C = bw.cout;
   launch_block_transform(p.hB, C, p.xd, C, B, H, W, C, k.dct_block, bw.dct, 0, 0.f, 1.f, s);
   IGemm g;
   g.B = B; g.H = H; g.W = W; g.bs = k.dct_block; g.low = k.low_size;
@@ -405,7 +410,7 @@ void Context::freq_dct(const BlockW& bw, int H, int W, hipStream_t s) {
 void Context::avif_transform(const AvifTransformW& at, const float* x, int ldx, int C, int H, int W, float* T,
                              float* tmp, float* out, int ldo, const float* rowscale, const float* res, int ldres,
                              hipStream_t s) {
-  const int B = plan_.B;
+  const int B = fb_;
   launch_block_transform(x, ldx, T, C, B, H, W, C, 8, at.tw, 1, 0.f, 1.f, s);
   IGemm g; g.B = B; g.H = H; g.W = W;
   IGemm a = g; a.A = T; a.lda = C; a.epi_act = ACT_RELU; a.out = tmp; a.ldo = C;
@@ -418,7 +423,7 @@ void Context::avif_transform(const AvifTransformW& at, const float* x, int ldx, 
 // AVIF frequency block (avif_inference.py:222-256).  In: plan_.hB.  Out: plan_.S = x + xt*avg*color*edge.
 void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
   Plan& p = plan_;
-  const int B = p.B, C = bw.cout;
+  const int B = fb_, C = bw.cout;
   const int64_t M = (int64_t)B * H * W;
   avif_transform(bw.at, p.hB, C, C, H, W, p.xd, p.hid, p.xt, C, nullptr, nullptr, 0, s);
   const int scales[4] = {1, 2, 4, 8};
@@ -459,7 +464,7 @@ void Context::conv16(const ConvW& cw, IGemm p, hipStream_t s) {
 void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest,
                           hipStream_t s) {
   Plan& p = plan_;
-  const int B = p.B, C = bw.cout, HW = H * W;
+  const int B = fb_, C = bw.cout, HW = H * W;
   const int cin8 = round_up(bw.cin, 8);
   IGemm g; g.B = B; g.H = H; g.W = W; g.bs = k.dct_block; g.low = k.low_size;
   // norm1 -> conv1 (+ bias + time projection)
@@ -529,7 +534,7 @@ void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int 
                         hipStream_t s) {
   if (use_gemm16()) { run_block16(bw, in, ldin, H, W, dest, lddest, s); return; }
   Plan& p = plan_;
-  const int B = p.B, C = bw.cout;
+  const int B = fb_, C = bw.cout;
   IGemm g; g.B = B; g.H = H; g.W = W;
   // norm1 -> conv1 (+ bias + time projection)            webp_inference.py:304-309
   launch_gn_scale_shift(in, ldin, B, H * W, bw.cin, gn_groups(bw.cin), bw.n1g, bw.n1b, p.gn_partial, p.sc1, p.sh1, s);
@@ -572,7 +577,7 @@ void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int 
 
 void Context::forward(const float* x, const float* t, const float* cl, float* out, hipStream_t s) {
   Plan& p = plan_;
-  const int B = p.B, H = p.H, W = p.W;
+  const int B = fb_, H = p.H, W = p.W;
   prof_begin(PROF_FWD, 0.0, s);
   launch_nchw3_to_nhwc4(x, p.x4, B, H, W, s);
   launch_time_embed(t, B, tw_, p.hidden, p.temb, p.tproj, s);
@@ -626,6 +631,7 @@ void Context::predict(const float* x, const float* t, const float* cl, float* ou
   if (!finalized_) throw std::logic_error("predict before finalize_weights");
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
   ensure_plan(B, H, W);
+  fb_ = B;
   const bool own = (s == nullptr);
   hipStream_t st = own ? stream_ : s;
   Plan& p = plan_;
@@ -657,22 +663,23 @@ void Context::predict(const float* x, const float* t, const float* cl, float* ou
 }
 
 // ------------------------------------------------------------------------------------------------ phase fix
-void Context::phase_prepare(const float* y, int B, int H, int W, hipStream_t s) {
+// `off` = element offset of the image sub-batch inside the per-plan DFT buffers (micro-batch lanes of the loop)
+void Context::phase_prepare(const float* y, int B, int H, int W, hipStream_t s, size_t off) {
   Plan& p = plan_;
   DftPlan d{p.tw_ch, p.tw_sh, H, p.tw_cw, p.tw_sw, W};
   const int P = B * 3;
   // dft[0], dft[1] = unit phase of fft2(y)
-  launch_dft2_forward(y, p.dft[0], p.dft[1], p.dft[4], p.dft[5], P, d, s);
-  launch_unit_phase(p.dft[0], p.dft[1], (int64_t)P * H * W, s);
+  launch_dft2_forward(y, p.dft[0] + off, p.dft[1] + off, p.dft[4] + off, p.dft[5] + off, P, d, s);
+  launch_unit_phase(p.dft[0] + off, p.dft[1] + off, (int64_t)P * H * W, s);
 }
 
-void Context::phase_fix(float* x, int B, int H, int W, double alpha, hipStream_t s) {
+void Context::phase_fix(float* x, int B, int H, int W, double alpha, hipStream_t s, size_t off) {
   Plan& p = plan_;
   DftPlan d{p.tw_ch, p.tw_sh, H, p.tw_cw, p.tw_sw, W};
   const int P = B * 3;
-  launch_dft2_forward(x, p.dft[2], p.dft[3], p.dft[4], p.dft[5], P, d, s);
-  launch_phase_apply_inverse(x, p.dft[2], p.dft[3], p.dft[0], p.dft[1], p.dft[4], p.dft[5], p.dft[6], p.dft[7], x, P,
-                             d, (float)alpha, (float)(1.0 - alpha), s);
+  launch_dft2_forward(x, p.dft[2] + off, p.dft[3] + off, p.dft[4] + off, p.dft[5] + off, P, d, s);
+  launch_phase_apply_inverse(x, p.dft[2] + off, p.dft[3] + off, p.dft[0] + off, p.dft[1] + off, p.dft[4] + off,
+                             p.dft[5] + off, p.dft[6] + off, p.dft[7] + off, x, P, d, (float)alpha, (float)(1.0 - alpha), s);
 }
 
 void Context::phase_consistency(const float* x, const float* ref, float* out, int B, int H, int W, double alpha) {
@@ -680,9 +687,9 @@ void Context::phase_consistency(const float* x, const float* ref, float* out, in
   ensure_plan(B, H, W);
   Plan& p = plan_;
   const size_t n = (size_t)B * 3 * H * W;
-  phase_prepare(ref, B, H, W, stream_);
+  phase_prepare(ref, B, H, W, stream_, 0);
   DDPMIR_HIP_CHECK(hipMemcpyAsync(p.dft[8], x, n * 4, hipMemcpyDeviceToDevice, stream_));
-  phase_fix(p.dft[8], B, H, W, alpha, stream_);
+  phase_fix(p.dft[8], B, H, W, alpha, stream_, 0);
   DDPMIR_HIP_CHECK(hipMemcpyAsync(out, p.dft[8], n * 4, hipMemcpyDeviceToDevice, stream_));
   DDPMIR_HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -714,50 +721,75 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
   const double alpha = opts->phase_alpha >= 0.0 ? opts->phase_alpha : k.phase_alpha;
   const float one_minus_eta_b = (float)(1.0 - eta_b);   // Python forms (1 - eta_b) in double (webp_inference.py:592)
   const bool do_phase = quality < phase_q;
-
   DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_y, y, n * 4, hipMemcpyDeviceToDevice, s));     // y = x_t.clone()
   DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_xt, y, n * 4, hipMemcpyDeviceToDevice, s));
-  if (do_phase) phase_prepare(p.s_y, B, H, W, s);
-  const bool graph = cfg.use_graph != 0;
   const int i_first = (opts->start_step >= 0 && opts->start_step < steps) ? opts->start_step : steps - 1;
   const int i_last = opts->num_steps > 0 ? std::max(0, i_first - opts->num_steps + 1) : 0;
-  for (int i = i_first; i >= i_last; --i) {
-    launch_fill_t(p.s_t, B, i, steps, s);
-    if (graph) {
-      predict(p.s_xt, p.s_t, p.s_t, p.s_theta, B, H, W, s);
-    } else {
-      forward(p.s_xt, p.s_t, p.s_t, p.s_theta, s);
+
+  // Host-codec families (WebP / AVIF, or JPEG through the callback): the batch is split into two micro-batch
+  // lanes that are software-pipelined -- while the host runs the codec of lane A, the GPU runs the U-Net
+  // forward of lane B, and lane A's next forward is enqueued before lane B's codec starts.  Images are
+  // independent, so the results are those of the unsplit batch.  The device JPEG codec needs no lanes.
+  static const bool no_overlap = getenv("DDPMIR_NO_OVERLAP") != nullptr;
+  const int nl = (!dev_codec && B >= 2 && (B % 2) == 0 && !no_overlap) ? 2 : 1;
+  const int nb = B / nl;
+  const size_t nh = (size_t)nb * 3 * H * W;                 // elements per lane
+  if (do_phase)
+    for (int l = 0; l < nl; ++l) phase_prepare(p.s_y + l * nh, nb, H, W, s, l * nh);
+
+  auto enqueue_forward = [&](int l, int i) {   // G(l, i): t, U-Net forward, uint8 quantise, (D2H)
+    fb_ = nb;
+    launch_fill_t(p.s_t + l * nb, nb, i, steps, s);
+    forward(p.s_xt + l * nh, p.s_t + l * nb, p.s_t + l * nb, p.s_theta + l * nh, s);
+    launch_quantize_u8(p.s_theta + l * nh, p.s_u8 + l * nh, (int64_t)nh, s);
+    if (!dev_codec) {
+      DDPMIR_HIP_CHECK(hipMemcpyAsync(pin_in_ + l * nh, p.s_u8 + l * nh, nh, hipMemcpyDeviceToHost, s));
+      DDPMIR_HIP_CHECK(hipEventRecord(lane_ev_[l], s));
     }
-    launch_quantize_u8(p.s_theta, p.s_u8, (int64_t)n, s);
+  };
+  auto codec_and_update = [&](int l, int i) {  // C(l, i) on the host, then U(l, i) on the stream
     if (dev_codec) {
       // JPEG round trip stays on the device: no PCIe hop, no host synchronisation inside the loop
-      launch_jpeg_roundtrip(p.s_u8, p.s_dec, p.s_jpeg, B, H, W, quality, s);
+      launch_jpeg_roundtrip(p.s_u8 + l * nh, p.s_dec + l * nh, p.s_jpeg, nb, H, W, quality, s);
     } else {
-      DDPMIR_HIP_CHECK(hipMemcpyAsync(pin_in_, p.s_u8, n, hipMemcpyDeviceToHost, s));
-      DDPMIR_HIP_CHECK(hipStreamSynchronize(s));
-      int rc = opts->codec(opts->codec_user, pin_in_, pin_out_, B, H, W, quality);
+      DDPMIR_HIP_CHECK(hipEventSynchronize(lane_ev_[l]));
+      int rc = opts->codec(opts->codec_user, pin_in_ + l * nh, pin_out_ + l * nh, nb, H, W, quality);
       if (rc != 0) throw std::runtime_error("codec callback failed with code " + std::to_string(rc));
-      DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_dec, pin_out_, n, hipMemcpyHostToDevice, s));
+      DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_dec + l * nh, pin_out_ + l * nh, nh, hipMemcpyHostToDevice, s));
     }
     const float* noise = nullptr;
     if (i > 0) {
-      if (opts->noise) noise = opts->noise + (size_t)i * n;
+      if (opts->noise) noise = opts->noise + (size_t)i * n + l * nh;
       else {
         // counter = (step, global element index): results do not depend on how the batch is sharded
-        launch_randn(p.s_noise, (int64_t)n, opts->seed + (uint64_t)i * 0x9E3779B97F4A7C15ull,
-                     opts->image_offset * (uint64_t)(3 * H * W) / 4, s);
-        noise = p.s_noise;
+        launch_randn(p.s_noise + l * nh, (int64_t)nh, opts->seed + (uint64_t)i * 0x9E3779B97F4A7C15ull,
+                     (opts->image_offset + (uint64_t)l * nb) * (uint64_t)(3 * H * W) / 4, s);
+        noise = p.s_noise + l * nh;
       }
     }
-    launch_ddrm_update(p.s_theta, p.s_dec, p.s_y, noise, p.s_xt, (int64_t)3 * H * W, B, (float)eta, (float)eta_b, one_minus_eta_b,
-                       coeff, i, steps, i == 0 ? 1 : 0, s);
-    if (i > 0 && do_phase && (i % every) == 0) phase_fix(p.s_xt, B, H, W, alpha, s);
+    launch_ddrm_update(p.s_theta + l * nh, p.s_dec + l * nh, p.s_y + l * nh, noise, p.s_xt + l * nh, (int64_t)3 * H * W, nb,
+                       (float)eta, (float)eta_b, one_minus_eta_b, coeff, i, steps, i == 0 ? 1 : 0, s);
+    if (i > 0 && do_phase && (i % every) == 0) phase_fix(p.s_xt + l * nh, nb, H, W, alpha, s, l * nh);
     if (opts->trace) {
-      float* tr = opts->trace + (size_t)(i_first - i) * 2 * n;
-      DDPMIR_HIP_CHECK(hipMemcpyAsync(tr, p.s_theta, n * 4, hipMemcpyDeviceToDevice, s));
-      DDPMIR_HIP_CHECK(hipMemcpyAsync(tr + n, p.s_xt, n * 4, hipMemcpyDeviceToDevice, s));
+      float* tr = opts->trace + (size_t)(i_first - i) * 2 * n + l * nh;
+      DDPMIR_HIP_CHECK(hipMemcpyAsync(tr, p.s_theta + l * nh, nh * 4, hipMemcpyDeviceToDevice, s));
+      DDPMIR_HIP_CHECK(hipMemcpyAsync(tr + n, p.s_xt + l * nh, nh * 4, hipMemcpyDeviceToDevice, s));
     }
+  };
+
+  try {
+    for (int l = 0; l < nl; ++l) enqueue_forward(l, i_first);
+    for (int i = i_first; i >= i_last; --i)
+      for (int l = 0; l < nl; ++l) {
+        codec_and_update(l, i);
+        if (i - 1 >= i_last) enqueue_forward(l, i - 1);
+      }
+  } catch (...) {
+    fb_ = B;
+    (void)hipStreamSynchronize(s);
+    throw;
   }
+  fb_ = B;
   DDPMIR_HIP_CHECK(hipMemcpyAsync(out, p.s_xt, n * 4, hipMemcpyDeviceToDevice, s));
   DDPMIR_HIP_CHECK(hipStreamSynchronize(s));
 }

@@ -72,3 +72,61 @@ def test_restoration(model, sampler, images, quality_levels=None, output_dir=Non
         with open(os.path.join(output_dir, "metrics_summary.json"), "w") as f:
             json.dump({str(k): v for k, v in results.items()}, f, indent=2)
     return results
+
+
+def _load_image_dir(path, size, limit):
+    """ImageFolderFlat + Resize + ToTensor + Normalize(0.5, 0.5) of webp_inference.py:32-58, as [1,3,S,S] tensors."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    names = sorted(f for f in os.listdir(path) if f.lower().endswith((".png", ".jpg", ".jpeg", ".bmp", ".webp")))
+    for f in names[:limit]:
+        im = Image.open(os.path.join(path, f)).convert("RGB").resize((size, size), Image.BILINEAR)
+        a = torch.from_numpy(np.asarray(im, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)
+        yield a.sub(0.5).div(0.5).unsqueeze(0)
+
+
+def main(argv=None):
+    """CLI mirror of `python webp_inference.py` / `avif_inference.py` main(): restore a folder of images (or a
+    synthetic set) at several qualities and write metrics_summary.json.  Multi-GPU: launch with torch.distributed.run."""
+    import argparse
+    import torch
+    from . import dist as D
+    from . import synth
+    from .model import MODEL_BY_ARCH, load_checkpoint
+    from .sampler import SAMPLER_BY_ARCH
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--arch", choices=list(spec.ARCH_NAMES), default="webp")
+    ap.add_argument("--checkpoint", default=None, help="best_ddrm_*_model.pth (state_dict or {'model_state_dict': ...}); "
+                                                        "omit for synthetic weights")
+    ap.add_argument("--images", default=None, help="folder of images; omit for synthetic images")
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--num-images", type=int, default=8)
+    ap.add_argument("--qualities", type=int, nargs="*", default=None)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--output-dir", default="./restoration_results")
+    args = ap.parse_args(argv)
+    env = D.init_from_env()
+    dev = torch.device("cuda", env.local_rank)
+    arch = spec.ARCH_NAMES[args.arch]
+    model = MODEL_BY_ARCH[arch](device=dev, dtype=args.dtype)
+    if args.checkpoint:
+        D.load_weights_broadcast(model, lambda: (lambda c: c["model_state_dict"] if "model_state_dict" in c else c)(
+            torch.load(args.checkpoint, map_location="cpu")), env)
+    else:
+        D.load_weights_broadcast(model, lambda: synth.synth_state_dict(arch), env)
+    print(f"Model parameters: {sum(p.numel() for p in model.parameters()):,}")
+    if args.images:
+        batches = list(_load_image_dir(args.images, args.size, args.num_images))
+    else:
+        batches = [torch.from_numpy(synth.synth_images(1, args.size, seed=1000 + i)) for i in range(args.num_images)]
+    res = test_restoration(model, SAMPLER_BY_ARCH[arch](model), batches, args.qualities, args.output_dir, env=env)
+    if env.rank == 0:
+        for q, r in res.items():
+            print(f"quality {q:3d}: PSNR {r['compressed_psnr']:.2f} -> {r['restored_psnr']:.2f} dB "
+                  f"(gain {r['psnr_gain']:+.2f}), L2 {r['compressed_l2']:.4f} -> {r['restored_l2']:.4f}, n={r['count']}")
+    return res
+
+
+if __name__ == "__main__":
+    main()
