@@ -128,7 +128,9 @@ __global__ __launch_bounds__(256) void pack_qkv_bf16(const float* __restrict__ q
 // ------------------------------------------------------------------------------------------------ flash
 constexpr float RESCALE_THR = 20.0f;   // log2 units
 
-template <int D, int QS, int TS, int WPS = 0>
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int D, int QS, int TS, int WPS = 0, int DMA = 1>
 __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
                                                   const float* __restrict__ Kmax, float* __restrict__ out, int ldo,
                                                   int N, int NT, int heads, int nqb, int npairs,
@@ -220,13 +222,32 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
       if (i * 256 + tid < SG::CHUNKS) *reinterpret_cast<float4*>(dst + ((size_t)i * 256 + tid) * 16) = stg[i];
   };
 
-  gload(0);
-  lstore(0);
+  // DMA staging: the packed K/V images are a linear copy, so each stage is fetched by direct-to-LDS loads
+  // (no VGPR staging, no ds_write pass); issued at the top of the previous stage, retired by the stage barrier.
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  auto dma = [&](int stage, int buf) {
+    if (tid < TS) stg_km = (stage * TS + tid < NT) ? gkmax[stage * TS + tid] : 0.f;
+    const unsigned char* src = gkv + (size_t)stage * SG::STAGE_BYTES;
+    const unsigned ldsb = lds0 + buf * SG::STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < SG::CPT; ++i) {
+      const size_t off = ((size_t)i * 256 + tid) * 16;
+      if ((size_t)stage * SG::STAGE_BYTES + off < total_bytes && i * 256 + tid < SG::CHUNKS)
+        __builtin_amdgcn_global_load_lds((const void*)(src + off), (lds_ptr_t)(size_t)(ldsb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  if (DMA) {
+    dma(0, 0);
+    if (tid < TS) kmax_lds[tid] = stg_km;
+  } else {
+    gload(0);
+    lstore(0);
+  }
   __syncthreads();
 
   for (int st = 0; st < nstages; ++st) {
     const int buf = st & 1;
-    if (st + 1 < nstages) gload(st + 1);
+    if (st + 1 < nstages) { if (DMA) dma(st + 1, buf ^ 1); else gload(st + 1); }
     const unsigned char* sb = lds + buf * SG::STAGE_BYTES;
     const int tiles_here = min(TS, NT - st * TS);
     // Stage-level bound: if |q| * max_k|k| over the WHOLE stage cannot exceed the running max by the threshold,
@@ -339,8 +360,10 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
       }
     }
     if (st + 1 < nstages) {
-      lstore(buf ^ 1);     // buffer buf^1 was last read in stage st-1, fenced by that stage's barrier
-      __syncthreads();
+      // buffer buf^1 was last read in stage st-1, fenced by that stage's barrier
+      if (DMA) { if (tid < TS) kmax_lds[(buf ^ 1) * TS + tid] = stg_km; }
+      else lstore(buf ^ 1);
+      __syncthreads();     // with LDS-DMA outstanding this also waits vmcnt(0): every wave's share has landed
     }
   }
 
@@ -377,7 +400,7 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
   }
 }
 
-template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT, int WPS = 0>
+template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT, int WPS = 0, int DMA = 1>
 void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* ws, hipStream_t s,
                void* out16) {
   using G = AttnGeom<D>;
@@ -394,11 +417,11 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
   const int nqb = (N + 128 * QS - 1) / (128 * QS);
   static bool attr_set = false;
   if (!attr_set) {
-    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16<D, QS, TS, WPS>),
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16<D, QS, TS, WPS, DMA>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SG::STAGE_BYTES + 2 * TS * 4));
     attr_set = true;
   }
-  hipLaunchKernelGGL((flash_bf16<D, QS, TS, WPS>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
+  hipLaunchKernelGGL((flash_bf16<D, QS, TS, WPS, DMA>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
                      out, ldo, N, NT, heads, nqb, BH, reinterpret_cast<__bf16*>(out16));
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
@@ -440,17 +463,18 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
       case 4: run_flash<16, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 5: run_flash<16, 2, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 6: run_flash<16, 2, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 7: run_flash<16, 1, 8, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 8: run_flash<16, 1, 4, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 9: run_flash<16, 2, 8, 3>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 7: run_flash<16, 2, 16, 0, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 8: run_flash<16, 2, 8, 0, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 9: run_flash<16, 1, 16, 0, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       default: break;
     }
   }
   switch (C / heads) {
     // head_dim <= 16 is bound by v_exp issue: two query sub-tiles per wave share every K/V fragment read and give
     // the scheduler two independent exp/pack/PV chains (A/B on one device: 7.92 vs 8.49 ms at N = 65 536)
-    case 8: run_flash<8, 2>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
-    case 16: run_flash<16, 2>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
+    // ... and 16-tile (512-key) stages: one barrier per 32 K scores per wave (A/B: TS 4/8/16 = 8.86/7.66/7.24 ms)
+    case 8: run_flash<8, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
+    case 16: run_flash<16, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     case 32: run_flash<32, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     case 64: run_flash<64, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     case 128: run_flash<128, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
