@@ -154,7 +154,7 @@ def main():
         }
         if roof:
             line["roofline"] = roof
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and env.world == 1:     # the CPU baseline is timed at N=1 only
             line["cpu_baseline"] = cpu_baseline(R, q)
         print(json.dumps(line), flush=True)
     D.barrier(env)

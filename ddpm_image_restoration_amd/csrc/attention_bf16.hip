@@ -43,7 +43,7 @@ struct AttnGeom {
   static constexpr int VT_BYTES = DT * 2 * 2 * RV * 16;
   static constexpr int TILE_BYTES = KT_BYTES + VT_BYTES;
   // default tiles per LDS stage: ~16 KiB per buffer
-  static constexpr int TS_DEFAULT = D <= 16 ? 8 : (D == 32 ? 4 : (D == 64 ? 2 : 1));
+  static constexpr int TS_DEFAULT = D <= 16 ? 8 : (D == 32 ? 8 : (D == 64 ? 4 : 2));
 };
 
 template <int D, int TS>
@@ -183,9 +183,17 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
 
   f32x16 o[QS][G::DT], negm[QS];
   float lsum[QS];
+  // head_dim >= 32 has no spare accumulator row for the ones trick: the softmax denominator comes from one more
+  // MFMA per k-step with an all-ones A operand (8 VALU issue cycles instead of a 16-add chain per tile)
+  f32x16 osum[QS];
+  bf16x8 ones8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones8[j] = (__bf16)1.0f;
 #pragma unroll
   for (int u = 0; u < QS; ++u) {
     lsum[u] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) osum[u][r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) negm[u][r] = 0.f;
 #pragma unroll
@@ -280,10 +288,13 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float p = __builtin_amdgcn_exp2f(s[r]);
-            if (!G::ONES) ps += p;
             pb[r >> 3][r & 7] = (__bf16)p;
           }
-          if (!G::ONES) lsum[u] += ps;
+          (void)ps;
+          if (!G::ONES) {
+            osum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[0], osum[u], 0, 0, 0);
+            osum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[1], osum[u], 0, 0, 0);
+          }
 #pragma unroll
           for (int dt = 0; dt < G::DT; ++dt) {
             o[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], pb[0], o[u][dt], 0, 0, 0);
@@ -336,6 +347,10 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
             if (!first) {
               const float f = exp2f(-delta);
               lsum[u] *= f;
+              if (!G::ONES) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) osum[u][r] *= f;
+              }
 #pragma unroll
               for (int dt = 0; dt < G::DT; ++dt)
 #pragma unroll
@@ -348,10 +363,13 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float p = __builtin_amdgcn_exp2f(s[r]);
-          if (!G::ONES) ps += p;
           pb[r >> 3][r & 7] = (__bf16)p;
         }
-        if (!G::ONES) lsum[u] += ps;
+        (void)ps;
+        if (!G::ONES) {
+          osum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[0], osum[u], 0, 0, 0);
+          osum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[1], osum[u], 0, 0, 0);
+        }
 #pragma unroll
         for (int dt = 0; dt < G::DT; ++dt) {
           o[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], pb[0], o[u][dt], 0, 0, 0);
@@ -372,7 +390,7 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
   for (int u = 0; u < QS; ++u) {
     float l;
     if (G::ONES) l = __shfl(o[u][0][(D / 8) * 4], lr);   // row D of O^T: register (D/8)*4 of lane half 0
-    else l = lsum[u] + __shfl_xor(lsum[u], 32);
+    else l = osum[u][0];   // every row of the ones-product holds the full sum over keys of this lane's query
     const float inv = 1.0f / l;
     const int qr = q0 + 32 * u + lr;
     if (qr < N) {
