@@ -135,7 +135,12 @@ def main():
     if a_n > 0 and a_ms > 0:
         achieved = a_fl / (a_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "flash attention, N=%d tokens, head_dim 16 (down1/up5)" % (R * R),
-                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                # HBM bytes per launch from the committed PMC passes (profiles/r01_attn_bf16_pmc_{fetch,write}.csv:
+                # (FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE/2 [the model writes bf16]) KiB on a B=4 launch, scaled by B/4;
+                # not collected live
+                "traffic": (2 * 271936.5 + 65536 / 2) * 1024 * (B / 4.0) if (args.dtype == "bf16" and R == 256) else None,
+                "valu_bound_note": "bound by v_exp_f32 issue (32 FLOP per exp at head_dim 16): VALU pipe ~80% busy, MFMA pipe ~39%",
                 "avg_launch_ms": a_ms / a_n, "launches": a_n, "forward_ms": (f_ms / f_n) if f_n else None}
 
     if env.rank == 0:

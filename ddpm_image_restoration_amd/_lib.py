@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libddpmir.so")
+LIB_PATH = os.environ.get("DDPMIR_LIB_PATH") or os.path.join(HERE, "libddpmir.so")   # override: A/B of two builds
 
 CODEC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int,
                        C.c_int)

@@ -267,30 +267,28 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
 #pragma unroll
     for (int u = 0; u < QS; ++u) fast = fast && !__any(fmaf(qn[u], smax, -m_run[u]) > RESCALE_THR);
     if (fast) {
-      for (int t = 0; t < tiles_here; ++t) {
+      // Two tiles per iteration with ping-pong (A/B) fragment registers: the LDS reads of the next tile are issued
+      // before the exp / pack / PV work of the current one, so the ds_read latency never sits in front of a tile.
+      bf16x8 kA[G::KC], vA[G::DT][2], kB[G::KC], vB[G::DT][2];
+      auto fetch = [&](int t, bf16x8 (&k_)[G::KC], bf16x8 (&v_)[G::DT][2]) {
         const unsigned char* tb = sb + t * G::TILE_BYTES;
-        bf16x8 kf[G::KC];
 #pragma unroll
-        for (int c = 0; c < G::KC; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(tb + c * 1024 + lane * 16);
-        bf16x8 vf[G::DT][2];
+        for (int c = 0; c < G::KC; ++c) k_[c] = *reinterpret_cast<const bf16x8*>(tb + c * 1024 + lane * 16);
 #pragma unroll
         for (int dt = 0; dt < G::DT; ++dt)
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
-            vf[dt][s] = *reinterpret_cast<const bf16x8*>(tb + G::KT_BYTES + ((dt * 2 + s) * 2 + lh) * (G::RV * 16) + vrow * 16);
+          for (int s2 = 0; s2 < 2; ++s2)
+            v_[dt][s2] = *reinterpret_cast<const bf16x8*>(tb + G::KT_BYTES + ((dt * 2 + s2) * 2 + lh) * (G::RV * 16) + vrow * 16);
+      };
+      auto process = [&](const bf16x8 (&kf)[G::KC], const bf16x8 (&vf)[G::DT][2]) {
 #pragma unroll
         for (int u = 0; u < QS; ++u) {
           f32x16 s = negm[u];
 #pragma unroll
           for (int c = 0; c < G::KC; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[u][c], s, 0, 0, 0);
           bf16x8 pb[2];
-          float ps = 0.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float p = __builtin_amdgcn_exp2f(s[r]);
-            pb[r >> 3][r & 7] = (__bf16)p;
-          }
-          (void)ps;
+          for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(s[r]);
           if (!G::ONES) {
             osum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[0], osum[u], 0, 0, 0);
             osum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[1], osum[u], 0, 0, 0);
@@ -301,7 +299,16 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
             o[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][1], pb[1], o[u][dt], 0, 0, 0);
           }
         }
+      };
+      fetch(0, kA, vA);
+      int t = 0;
+      for (; t + 1 < tiles_here; t += 2) {
+        fetch(t + 1, kB, vB);
+        process(kA, vA);
+        if (t + 2 < tiles_here) fetch(t + 2, kA, vA);
+        process(kB, vB);
       }
+      if (t < tiles_here) process(kA, vA);
     } else
     for (int t = 0; t < tiles_here; ++t) {
       const int kt = st * TS + t;

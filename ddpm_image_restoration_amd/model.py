@@ -106,6 +106,26 @@ class _RestorationModel:
         _lib.check(self._lib, self._ctx, rc, "finalize_weights")
         self._loaded = True
 
+    def save_packed(self, path: str):
+        """Checkpoint converter output: the packed, kernel-ready weight blob (OIHW -> [tap][Cout][Cin], bf16 copies,
+        concatenated time projections) of a model whose state dict was loaded and validated by name."""
+        torch = _torch()
+        if not self._loaded:
+            raise RuntimeError("load_state_dict() first")
+        if self._blob is None:
+            raise RuntimeError("save_packed needs the blob to be caller-owned: use convert_checkpoint()")
+        np.save(path, self._blob.cpu().numpy(), allow_pickle=False)
+
+    def load_packed(self, path: str):
+        """Adopt a blob written by save_packed() (same model family and dtype): no per-tensor repacking."""
+        torch = _torch()
+        arr = np.load(path if path.endswith(".npy") else path + ".npy", allow_pickle=False)
+        if arr.dtype != np.uint8 or arr.size != self.weight_blob_bytes():
+            raise RuntimeError(f"packed blob does not match this model: {arr.size} vs {self.weight_blob_bytes()} bytes")
+        blob = torch.from_numpy(arr).to(self.device)
+        self.finalize(blob=blob, fill=False)
+        return self
+
     def weight_blob_bytes(self) -> int:
         return int(self._lib.ddpmir_weight_blob_bytes(self._ctx))
 
@@ -168,6 +188,25 @@ class AVIFDiffusionModel(_RestorationModel):
 
 MODEL_BY_ARCH = {spec.ARCH_WEBP: WebPDiffusionModel, spec.ARCH_JPEG: JPEGDiffusionModel,
                  spec.ARCH_AVIF: AVIFDiffusionModel}
+
+
+def convert_checkpoint(model: _RestorationModel, ckpt_path: str, out_path: str):
+    """best_ddrm_*_model.pth -> packed blob file: validates every state-dict name/shape, packs on the
+    device into a caller-owned blob and writes it; `model.load_packed(out_path)` restores it on any rank."""
+    torch = _torch()
+    ckpt = torch.load(ckpt_path, map_location="cpu")
+    sd = ckpt["model_state_dict"] if isinstance(ckpt, dict) and "model_state_dict" in ckpt else ckpt
+    want = spec.state_spec(model.ARCH)
+    missing = [k for k in want if k not in sd]
+    unexpected = [k for k in sd if k not in want]
+    if missing or unexpected:
+        raise RuntimeError(f"state_dict mismatch: missing {missing[:5]} unexpected {unexpected[:5]}")
+    blob = torch.empty(model.weight_blob_bytes(), dtype=torch.uint8, device=model.device)
+    for k in want:
+        model._load_one(k, sd[k])
+    model.finalize(blob=blob, fill=True)
+    model.save_packed(out_path)
+    return model
 
 
 def load_checkpoint(model: _RestorationModel, path: str):

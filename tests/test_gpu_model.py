@@ -236,3 +236,25 @@ def test_weight_blob_adoption_matches_direct_load(golden, synth_state):
         else:   # bf16 mode sums split-K partials with float atomics: last-bit run-to-run differences
             assert (a - b).abs().max().item() < 1e-2
         assert other.param_count() == spec.param_count(spec.ARCH_JPEG)
+
+
+def test_checkpoint_converter_roundtrip(tmp_path, golden, synth_state):
+    """8(f)4: .pth state dict -> packed blob file -> model; wrapped and bare state dicts; name validation."""
+    import torch
+    from ddpm_image_restoration_amd.model import WebPDiffusionModel, convert_checkpoint, load_checkpoint
+    g = golden("webp")
+    dev = torch.device("cuda", 0)
+    sd = {k: torch.from_numpy(v) for k, v in synth_state(spec.ARCH_WEBP).items()}
+    torch.save({"epoch": 3, "model_state_dict": sd}, tmp_path / "wrapped.pth")
+    torch.save(sd, tmp_path / "bare.pth")
+    a = load_checkpoint(WebPDiffusionModel(device=dev), str(tmp_path / "wrapped.pth"))
+    convert_checkpoint(WebPDiffusionModel(device=dev), str(tmp_path / "bare.pth"), str(tmp_path / "packed.npy"))
+    b = WebPDiffusionModel(device=dev).load_packed(str(tmp_path / "packed.npy"))
+    ya = a(tt(g["fwd32_x"]), tt(g["fwd32_t"]), tt(g["fwd32_cl"]))
+    yb = b(tt(g["fwd32_x"]), tt(g["fwd32_t"]), tt(g["fwd32_cl"]))
+    assert torch.equal(ya, yb)
+    assert np.abs(ya.cpu().numpy() - g["fwd32_y"]).max() < TOL
+    bad = dict(sd); bad.pop("down3.conv2.bias")
+    torch.save(bad, tmp_path / "bad.pth")
+    with pytest.raises(RuntimeError, match="missing"):
+        convert_checkpoint(WebPDiffusionModel(device=dev), str(tmp_path / "bad.pth"), str(tmp_path / "x.npy"))
