@@ -480,6 +480,16 @@ size_t attention_bf16_workspace(int B, int N, int C, int heads) {
 void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* workspace,
                            hipStream_t s, void* out16) {
   static const int var = [] { const char* e = getenv("DDPMIR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // tuning knob
+  if (C / heads == 32 && var >= 20) {   // head_dim 32 experiments
+    switch (var) {
+      case 20: run_flash<32, 1, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 21: run_flash<32, 1, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 22: run_flash<32, 2, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 23: run_flash<32, 2, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 24: run_flash<32, 1, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      default: break;
+    }
+  }
   if (C / heads == 16 && var != 0) {
     switch (var) {
       case 1: run_flash<16, 1, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;

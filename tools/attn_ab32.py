@@ -1,0 +1,11 @@
+import sys, os, subprocess
+variants = sys.argv[1].split(",")
+code = "import os,sys; sys.path.insert(0,'.'); from ddpm_image_restoration_amd import ops; print(min(ops.attention_time(16,16384,128,4,1,3) for _ in range(2)))"
+res = {v: [] for v in variants}
+for rnd in range(3):
+    for v in variants:
+        env = dict(os.environ, DDPMIR_ATTN_VARIANT=v)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip().split("\n")[-1]
+        res[v].append(float(out))
+for v in variants:
+    print(f"variant {v}: min {min(res[v]):.3f} ms  all {['%.3f' % x for x in res[v]]}", flush=True)
