@@ -1,7 +1,8 @@
 """Evaluation harness mirroring test_webp_restoration / test_avif_restoration (webp_inference.py:604-797,
 avif_inference.py:462-657): for every quality level compress -> pick steps -> restore -> score, and report the
 same JSON keys (`compressed_psnr` ... `restored_l2`).  PSNR and L2 are first-party formulas of the reference;
-SSIM/LPIPS/FID depend on third-party packages and stay optional in PyTorch.
+SSIM restates the published pytorch_msssim algorithm the reference calls (package absent here: parity unpinned);
+LPIPS/FID need pretrained AlexNet/Inception weights that cannot be fetched offline, so those keys are omitted.
 """
 from __future__ import annotations
 
@@ -40,6 +41,34 @@ def l2(a, b):
     return (torch.norm(a01 - b01) / math.sqrt(a01.numel())).item()
 
 
+def ssim(a, b, win_size=11, sigma=1.5, k1=0.01, k2=0.03):
+    """pytorch_msssim.ssim(x01, y01, data_range=1.0) as called at webp_inference.py:698: separable 11-tap Gaussian
+    (sigma 1.5, 'valid'), per-channel SSIM map averaged over space, then over channels and batch.  A spatial dim
+    smaller than the window is left unsmoothed, as the package does."""
+    import torch
+    import torch.nn.functional as F
+    x = torch.clamp(a * 0.5 + 0.5, 0, 1).double()
+    y = torch.clamp(b * 0.5 + 0.5, 0, 1).double()
+    g = torch.arange(win_size, dtype=torch.float64, device=x.device) - win_size // 2
+    g = torch.exp(-(g ** 2) / (2 * sigma ** 2)); g = g / g.sum()
+    C = x.shape[1]
+
+    def blur(z):
+        if z.shape[2] >= win_size:
+            z = F.conv2d(z, g.view(1, 1, -1, 1).repeat(C, 1, 1, 1), groups=C)
+        if z.shape[3] >= win_size:
+            z = F.conv2d(z, g.view(1, 1, 1, -1).repeat(C, 1, 1, 1), groups=C)
+        return z
+    c1, c2 = k1 ** 2, k2 ** 2
+    mu1, mu2 = blur(x), blur(y)
+    s1 = blur(x * x) - mu1 * mu1
+    s2 = blur(y * y) - mu2 * mu2
+    s12 = blur(x * y) - mu1 * mu2
+    cs = (2 * s12 + c2) / (s1 + s2 + c2)
+    m = ((2 * mu1 * mu2 + c1) / (mu1 * mu1 + mu2 * mu2 + c1)) * cs
+    return m.flatten(2).mean(-1).mean().item()
+
+
 def test_restoration(model, sampler, images, quality_levels=None, output_dir=None, seed=0, env=None):
     """images: iterable of [B,3,H,W] tensors in [-1,1].  Returns {quality: averaged metrics} like the reference's
     avg_results and writes metrics_summary.json when output_dir is given.  With a DistEnv the image list is
@@ -54,7 +83,7 @@ def test_restoration(model, sampler, images, quality_levels=None, output_dir=Non
         batches = batches[lo:hi]
     results = {}
     for q in qs:
-        acc = [0.0, 0.0, 0.0, 0.0, 0.0]
+        acc = [0.0] * 7
         for bi, x0 in enumerate(batches):
             x0 = x0.to(model.device)
             y = COMPRESS[arch](x0, q)
@@ -62,11 +91,13 @@ def test_restoration(model, sampler, images, quality_levels=None, output_dir=Non
             n = x0.shape[0]
             acc[0] += psnr(y, x0) * n; acc[1] += psnr(restored, x0) * n
             acc[2] += l2(y, x0) * n; acc[3] += l2(restored, x0) * n; acc[4] += n
+            acc[5] += ssim(y, x0) * n; acc[6] += ssim(restored, x0) * n
         if env is not None:
             acc = D.reduce_metrics(acc, env, device=model.device)
         n = max(acc[4], 1.0)
-        results[q] = {"compressed_psnr": acc[0] / n, "restored_psnr": acc[1] / n, "compressed_l2": acc[2] / n,
-                      "restored_l2": acc[3] / n, "psnr_gain": (acc[1] - acc[0]) / n, "count": int(acc[4])}
+        results[q] = {"compressed_psnr": acc[0] / n, "compressed_ssim": acc[5] / n, "compressed_l2": acc[2] / n,
+                      "restored_psnr": acc[1] / n, "restored_ssim": acc[6] / n, "restored_l2": acc[3] / n,
+                      "psnr_gain": (acc[1] - acc[0]) / n, "count": int(acc[4])}
     if output_dir and (env is None or env.rank == 0):
         os.makedirs(output_dir, exist_ok=True)
         with open(os.path.join(output_dir, "metrics_summary.json"), "w") as f:
@@ -124,7 +155,7 @@ def main(argv=None):
     if env.rank == 0:
         for q, r in res.items():
             print(f"quality {q:3d}: PSNR {r['compressed_psnr']:.2f} -> {r['restored_psnr']:.2f} dB "
-                  f"(gain {r['psnr_gain']:+.2f}), L2 {r['compressed_l2']:.4f} -> {r['restored_l2']:.4f}, n={r['count']}")
+                  f"(gain {r['psnr_gain']:+.2f}), SSIM {r['compressed_ssim']:.4f} -> {r['restored_ssim']:.4f}, L2 {r['compressed_l2']:.4f} -> {r['restored_l2']:.4f}, n={r['count']}")
     return res
 
 

@@ -1,4 +1,5 @@
 """CPU: host-side logic of the package -- state-dict table, synthetic generators, codec module, sharding."""
+import pytest
 import numpy as np
 
 from ddpm_image_restoration_amd import codec, dist, spec, synth
@@ -50,3 +51,30 @@ def test_harness_step_rule():
     # webp_inference.py:678-679 clamp(100-q, 20, 80); avif_inference.py:534-535 clamp(100-q, 15, 75)
     assert [steps_for_quality(spec.ARCH_WEBP, q) for q in (0, 10, 50, 90)] == [80, 80, 50, 20]
     assert [steps_for_quality(spec.ARCH_AVIF, q) for q in (1, 30, 90)] == [75, 70, 15]
+
+
+def test_harness_ssim_matches_independent_restatement():
+    """SSIM (pytorch_msssim algorithm, webp_inference.py:698) vs a scipy restatement; identity gives exactly 1."""
+    import numpy as np
+    import torch
+    from scipy.ndimage import correlate1d
+    from ddpm_image_restoration_amd.harness import ssim
+    rng = np.random.default_rng(5)
+    a = rng.uniform(-1, 1, (2, 3, 40, 24)).astype(np.float32)
+    b = np.clip(a + rng.normal(0, 0.2, a.shape), -1.2, 1.2).astype(np.float32)
+    g = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2)); g /= g.sum()
+
+    def blur(z):
+        z = correlate1d(z, g, axis=2, mode="constant")[:, :, 5:-5]
+        return correlate1d(z, g, axis=3, mode="constant")[:, :, :, 5:-5]
+    x = np.clip(a * 0.5 + 0.5, 0, 1).astype(np.float64); y = np.clip(b * 0.5 + 0.5, 0, 1).astype(np.float64)
+    mx, my = blur(x), blur(y)
+    sx, sy, sxy = blur(x * x) - mx * mx, blur(y * y) - my * my, blur(x * y) - mx * my
+    want = (((2 * mx * my + 1e-4) / (mx * mx + my * my + 1e-4)) * ((2 * sxy + 9e-4) / (sx + sy + 9e-4))).mean()
+    got = ssim(torch.from_numpy(a), torch.from_numpy(b))
+    assert abs(got - want) < 1e-9
+    assert ssim(torch.from_numpy(a), torch.from_numpy(a)) == pytest.approx(1.0, abs=1e-12)
+    assert abs(ssim(torch.from_numpy(a), torch.from_numpy(b)) - ssim(torch.from_numpy(b), torch.from_numpy(a))) < 1e-12
+    # a dim smaller than the window is left unsmoothed (pytorch_msssim behaviour)
+    small = torch.from_numpy(a[:, :, :8, :8])
+    assert ssim(small, small) == pytest.approx(1.0, abs=1e-12)
