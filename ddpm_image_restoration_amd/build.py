@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libddpmir.so")
 SOURCES = ["igemm.hip", "gemm16.hip", "attention.hip", "attention_bf16.hip", "pointwise.hip", "sampler_kernels.hip", "jpeg_sim.hip", "model.hip", "eps_unet.hip", "api.hip", "ops_api.hip"]
 # MFMA results feed VALU (softmax) directly: keep C/D in VGPRs instead of copying through AGPRs every tile
-VGPR_MFMA = {"attention_bf16.hip", "attention.hip"}
+VGPR_MFMA = {"attention_bf16.hip", "attention.hip", "gemm16.hip"}
 NO_CONTRACT = {"sampler_kernels.hip"}   # bit-exact uint8 truncation path: no fma contraction
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

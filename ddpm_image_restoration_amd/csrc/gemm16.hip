@@ -7,10 +7,11 @@
 // direct-to-LDS loads for a 3-stage ring and only waits with a counted vmcnt -- the loads of two K chunks stay
 // in flight across the barrier while the MFMAs of the current chunk run.
 //
-// LDS image per stage: A [128 rows][64 k] bf16, B [32*NT rows][64 k] bf16, 128-byte rows, no padding.
-// A DMA wave-instruction writes 64 lanes x 16 B linearly (8 rows), so the bank-conflict fix is an XOR swizzle on
-// the SOURCE address: LDS chunk p of row r holds global chunk p ^ ((r>>1)&7); the MFMA operand read applies the
-// same XOR (rule: linear destination + permuted source + permuted read).  Rows outside the image (3x3 halo),
+// LDS image per stage: A [128 rows][BK] bf16, B [32*NT rows][BK] bf16, unpadded rows of BK*2 bytes (BK = 32 or 64).
+// A DMA wave-instruction writes 64 lanes x 16 B linearly, so the bank-conflict fix is an XOR swizzle on the SOURCE
+// address: LDS chunk p of row r holds global chunk p ^ key(r), key = (r >> log2(rows per 256-B bank row)) mod
+// chunks-per-row, which makes every 16-lane group of a ds_read_b128 hit 16 distinct 16-byte slots; the MFMA operand
+// read applies the same XOR (rule: linear destination + permuted source + permuted read).  Rows outside the image (3x3 halo),
 // rows past M / Cout and channel chunks past Cin are fetched from a 16-byte zero page.
 #include <algorithm>
 
@@ -25,35 +26,46 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 namespace {
 
-constexpr int BM = 128, BK = 64, STAGES = 3, ROWB = BK * 2;   // 128-byte LDS rows
+constexpr int BM = 128, STAGES = 3;
 
-template <int NT>
+// BK = K elements per stage (64 or 32).  BK = 32 halves the stage so three workgroups fit one CU (48 KiB each):
+// one workgroup's barrier waits, LDS-read latency and epilogue overlap the MFMAs of the other two.
+template <int NT, int BK>
 __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int A_BYTES = BM * ROWB, B_BYTES = NT * 32 * ROWB, STAGE = A_BYTES + B_BYTES;
-  constexpr int LOADS = 4 + NT;                       // DMA instructions per thread per stage
+  constexpr int ROWB = BK * 2;                         // bytes per LDS row
+  constexpr int CPR = BK / 8;                          // 16-byte chunks per row
+  constexpr int RSH = BK == 64 ? 1 : 2;                // rows per 256-byte bank row = 1 << RSH
+  constexpr int BROWS = NT * 32 * CPR < 256 ? 256 / CPR : NT * 32;   // every thread issues >= 1 B piece
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BROWS * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int AL = BM * CPR / 256, BL = BROWS * CPR / 256;          // DMA instructions per thread per stage
+  constexpr int LOADS = AL + BL;
+  constexpr int KS = BK / 16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = p.B * p.H * p.W, HW = p.H * p.W;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * (NT * 32);
+  // XCD-aware placement: consecutive M tiles (which share 3x3 halo rows) run on the same XCD / L2
+  int bx = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+  const int m0 = bx * BM, n0 = blockIdx.y * (NT * 32);
   const int nck = (p.Cin + BK - 1) / BK;
   const int nit_all = p.taps * nck;
   const int nsplit = gridDim.z, sk = blockIdx.z;
   const int it0 = (int)((long long)nit_all * sk / nsplit), it1 = (int)((long long)nit_all * (sk + 1) / nsplit);
-  const int nit = it1 - it0;
+  const int nit = (p.dbg & 16) ? 0 : it1 - it0;
   const __bf16* A16 = reinterpret_cast<const __bf16*>(p.A16);
   const __bf16* W16 = reinterpret_cast<const __bf16*>(p.Wt16);
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zero16);
   const unsigned lds0 = (unsigned)(size_t)smem;
 
-  // per-thread DMA slots: A slot j covers LDS row (j*256 + tid)/8, chunk position (tid & 7)
-  int a_y[4], a_x[4];
-  bool a_ok[4];
-  size_t a_off[4];
-  int a_chunk[4];
+  // per-thread DMA slots: slot s = j*256 + tid covers LDS row s / CPR, chunk position s % CPR
+  int a_y[AL], a_x[AL];
+  bool a_ok[AL];
+  size_t a_off[AL];
+  int a_chunk[AL];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (j * 256 + tid) >> 3, pos = tid & 7;
+  for (int j = 0; j < AL; ++j) {
+    const int row = (j * 256 + tid) / CPR, pos = tid & (CPR - 1);
     const int m = m0 + row;
     const bool ok = m < M;
     const int mm = ok ? m : 0;
@@ -61,14 +73,14 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
     a_y[j] = rem / p.W; a_x[j] = rem - a_y[j] * p.W;
     a_ok[j] = ok;
     a_off[j] = (size_t)mm * p.lda16;
-    a_chunk[j] = pos ^ ((row >> 1) & 7);              // which 8-channel chunk of the row this slot holds
+    a_chunk[j] = pos ^ ((row >> RSH) & (CPR - 1));     // which 8-channel chunk of the row this slot holds
   }
-  int b_n[NT], b_chunk[NT];
+  int b_n[BL], b_chunk[BL];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int row = (j * 256 + tid) >> 3, pos = tid & 7;
-    b_n[j] = n0 + row;
-    b_chunk[j] = pos ^ ((row >> 1) & 7);
+  for (int j = 0; j < BL; ++j) {
+    const int row = (j * 256 + tid) / CPR, pos = tid & (CPR - 1);
+    b_n[j] = row < NT * 32 ? n0 + row : p.Cout;         // rows past the tile read the zero page
+    b_chunk[j] = pos ^ ((row >> RSH) & (CPR - 1));
   }
 
   auto issue = [&](int itl) {
@@ -78,15 +90,17 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
     int dy = 0, dx = 0;
     if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
     const unsigned sbase = lds0 + (itl % STAGES) * STAGE;
+    if (!(p.dbg & 1))
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < AL; ++j) {
       const int c = c0 + 8 * a_chunk[j];
       const bool ok = a_ok[j] && c < p.Cin && (unsigned)(a_y[j] + dy) < (unsigned)p.H && (unsigned)(a_x[j] + dx) < (unsigned)p.W;
       const void* g = ok ? (const void*)(A16 + a_off[j] + (ptrdiff_t)(dy * p.W + dx) * p.lda16 + c) : (const void*)zero;
       __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sbase + (j * 256 + wave * 64) * 16), 16, 0, 0);
     }
+    if (!(p.dbg & 2))
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
+    for (int j = 0; j < BL; ++j) {
       const int c = c0 + 8 * b_chunk[j];
       const bool ok = b_n[j] < p.Cout && c < p.Cin;
       const void* g = ok ? (const void*)(W16 + ((size_t)tap * p.Cout + b_n[j]) * p.Cin + c) : (const void*)zero;
@@ -102,7 +116,8 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
 
   const int lr = lane & 31, lh = lane >> 5;
   const int arow = wave * 32 + lr;
-  const int a_key = (arow >> 1) & 7, b_key = (lr >> 1) & 7;      // b rows: nt*32 + lr -> (row>>1)&7 == (lr>>1)&7
+  // b rows: nt*32 + lr -> the key only depends on lr because 32 is a multiple of (CPR << RSH)
+  const int a_key = (arow >> RSH) & (CPR - 1), b_key = (lr >> RSH) & (CPR - 1);
 
   if (nit > 0) issue(0);
   if (nit > 1) issue(1);
@@ -114,18 +129,23 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
     __builtin_amdgcn_s_barrier();
     if (it + 2 < nit) issue(it + 2);
     const unsigned char* st = smem + (it % STAGES) * STAGE;
+    // all operand fragments of the stage first (one LDS round trip), then the MFMAs back to back
+    bf16x8 af[KS], bfr[KS][NT];
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(st + arow * ROWB + (((2 * ks + lh) ^ a_key) << 4));
+    for (int ks = 0; ks < KS; ++ks) {
+      af[ks] = *reinterpret_cast<const bf16x8*>(st + arow * ROWB + (((2 * ks + lh) ^ a_key) << 4));
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(st + A_BYTES + (nt * 32 + lr) * ROWB + (((2 * ks + lh) ^ b_key) << 4));
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[nt], 0, 0, 0);
-      }
+      for (int nt = 0; nt < NT; ++nt)
+        bfr[ks][nt] = *reinterpret_cast<const bf16x8*>(st + A_BYTES + (nt * 32 + lr) * ROWB + (((2 * ks + lh) ^ b_key) << 4));
     }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bfr[ks][nt], acc[nt], 0, 0, 0);
   }
 
   // ------------------------------------------------------------------------------------------ epilogue
+  if ((p.dbg & 8) && acc[0][0] != 12345.f) return;
   const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE;
   const bool atomic = nsplit > 1;
   const bool lead = sk == 0;
@@ -151,51 +171,54 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
     }
     return;
   }
-  // coalesced: accumulators -> wave-private LDS tile -> 16-byte row-contiguous accesses
-  constexpr int BN = NT * 32, BNP = BN + 4;
+  // coalesced: accumulators -> wave-private LDS tile (HN column tiles at a time) -> 16-byte row-contiguous accesses
+  constexpr int HN = NT < 2 ? NT : 2, BNH = HN * 32, BNP = BNH + 4;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                         // all waves are done reading the stage buffers
   float* ct = reinterpret_cast<float*>(smem) + wave * 32 * BNP;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + nt * 32 + lr] = acc[nt][r];
-  constexpr int L4 = BN / 4, RPP = 64 / L4;
+  constexpr int L4 = BNH / 4, RPP = 64 / L4;
   const int c4 = lane % L4, rsub = lane / L4;
-  const int n = n0 + 4 * c4;
-  if (n >= p.Cout) return;
-  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
   __bf16* out16 = reinterpret_cast<__bf16*>(p.out16);
+#pragma unroll
+  for (int h = 0; h < NT / HN; ++h) {
+#pragma unroll
+    for (int q = 0; q < HN; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + q * 32 + lr] = acc[h * HN + q][r];
+    const int n = n0 + h * BNH + 4 * c4;
+    if (n >= p.Cout) continue;                          // Cout % 4 == 0: a float4 is all in or all out
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
 #pragma unroll 4
-  for (int pass = 0; pass < 32 / RPP; ++pass) {
-    const int row = pass * RPP + rsub;
-    const int m = m0 + wave * 32 + row;
-    if (m >= M) continue;
-    float4 v = *reinterpret_cast<const float4*>(ct + row * BNP + 4 * c4);
-    int b = 0, y = 0, x = 0;
-    if (need_pos) {
-      b = m / HW;
-      const int rem = m - b * HW;
-      y = rem / p.W;
-      x = rem - y * p.W;
-    }
-    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-    if (p.tb) { float4 t = *reinterpret_cast<const float4*>(p.tb + (size_t)b * p.ldtb + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-    if (p.epi_act != ACT_NONE) { v.x = act_apply(v.x, p.epi_act); v.y = act_apply(v.y, p.epi_act); v.z = act_apply(v.z, p.epi_act); v.w = act_apply(v.w, p.epi_act); }
-    if (p.mul) { float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + n); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
-    if (p.rowscale) { const float rs = p.rowscale[b]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
-    if (p.epi_mask != MASK_NONE) {
-      const bool lowp = is_low_freq(y, x, p.H, p.W, p.bs, p.low);
-      const bool keep = (p.epi_mask == MASK_LOW) ? lowp : !lowp;
-      if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-    if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + n) = v;
-    if (out16) {
-      bf16x4 o;
-      o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-      *reinterpret_cast<bf16x4*>(out16 + (size_t)m * p.ldo16 + n) = o;
+    for (int pass = 0; pass < 32 / RPP; ++pass) {
+      const int row = pass * RPP + rsub;
+      const int m = m0 + wave * 32 + row;
+      if (m >= M) continue;
+      float4 v = *reinterpret_cast<const float4*>(ct + row * BNP + 4 * c4);
+      int b = 0, y = 0, x = 0;
+      if (need_pos) {
+        b = m / HW;
+        const int rem = m - b * HW;
+        y = rem / p.W;
+        x = rem - y * p.W;
+      }
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      if (p.tb) { float4 t = *reinterpret_cast<const float4*>(p.tb + (size_t)b * p.ldtb + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      if (p.epi_act != ACT_NONE) { v.x = act_apply(v.x, p.epi_act); v.y = act_apply(v.y, p.epi_act); v.z = act_apply(v.z, p.epi_act); v.w = act_apply(v.w, p.epi_act); }
+      if (p.mul) { float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + n); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+      if (p.rowscale) { const float rs = p.rowscale[b]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+      if (p.epi_mask != MASK_NONE) {
+        const bool lowp = is_low_freq(y, x, p.H, p.W, p.bs, p.low);
+        const bool keep = (p.epi_mask == MASK_LOW) ? lowp : !lowp;
+        if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + n) = v;
+      if (out16) {
+        bf16x4 o;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(out16 + (size_t)m * p.ldo16 + n) = o;
+      }
     }
   }
 }
@@ -248,14 +271,17 @@ __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C
   }
 }
 
-template <int NT>
+template <int NT, int BK>
 void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
-  constexpr int STAGE = (BM + NT * 32) * ROWB;
-  constexpr int EPI = 4 * 32 * (NT * 32 + 4) * 4;
+  constexpr int CPR = BK / 8;
+  constexpr int BROWS = NT * 32 * CPR < 256 ? 256 / CPR : NT * 32;
+  constexpr int STAGE = (BM + BROWS) * BK * 2;
+  constexpr int HN = NT < 2 ? NT : 2;
+  constexpr int EPI = 4 * 32 * (HN * 32 + 4) * 4;
   constexpr int LDS = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
   static bool attr = false;
   if (!attr) {
-    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<NT>),
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<NT, BK>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr = true;
   }
@@ -264,14 +290,24 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   int nsplit = 1;
   const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && !p.out16 && p.out &&
                       (!p.res || p.res != p.out || p.ldres == p.ldo);
-  if (linear && gx * gy < 256 && nit >= 8) {
-    nsplit = std::min(std::min(16, nit / 4), cdiv(512, gx * gy));
+  if (linear && gx * gy < 256 && nit >= 8 * (64 / BK)) {
+    nsplit = std::min(std::min(16, nit / (4 * (64 / BK))), cdiv(512, gx * gy));
     if (nsplit < 1) nsplit = 1;
   }
   if (nsplit > 1 && !(p.res && p.res == p.out))
     hipLaunchKernelGGL(zero_rows16_k, dim3((unsigned)std::min<int64_t>(cdiv64(M * (p.Cout / 4), 256), 2048)), dim3(256), 0,
                        stream, p.out, p.ldo, M, p.Cout / 4);
-  hipLaunchKernelGGL(gemm16_kernel<NT>, dim3(gx, gy, nsplit), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((gemm16_kernel<NT, BK>), dim3(gx, gy, nsplit), dim3(256), LDS, stream, p);
+}
+
+template <int NT>
+void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
+  // BK = 32 (48 KiB, three workgroups per CU) when there are enough output tiles to co-schedule; the deep levels
+  // with few tiles go split-K, where the longer BK = 64 stage halves the barrier count (measured: DESIGN.md 4.2)
+  const int64_t tiles = cdiv64(M, BM) * cdiv(p.Cout, NT * 32);
+  const bool bk64 = (p.dbg & 32) ? true : (p.dbg & 64) ? false : tiles < 256;
+  if (bk64) launch_nt<NT, 64>(p, M, stream);
+  else launch_nt<NT, 32>(p, M, stream);
 }
 
 }  // namespace
@@ -285,9 +321,9 @@ void launch_gemm16(const IGemm& p, hipStream_t stream) {
   if (!gemm16_supported(p)) throw std::runtime_error("gemm16: unsupported operand layout");
   const int64_t M = (int64_t)p.B * p.H * p.W;
   if (M <= 0 || p.Cout <= 0) return;
-  if (p.Cout <= 32) launch_nt<1>(p, M, stream);
-  else if (p.Cout <= 64) launch_nt<2>(p, M, stream);
-  else launch_nt<4>(p, M, stream);
+  if (p.Cout <= 32) launch_bk<1>(p, M, stream);
+  else if (p.Cout <= 64) launch_bk<2>(p, M, stream);
+  else launch_bk<4>(p, M, stream);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

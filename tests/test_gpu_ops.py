@@ -283,4 +283,37 @@ def test_randn_moments_and_shard_independence(ops):
     assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
     assert abs(float((a ** 4).mean()) - 3) < 0.05
     b = ops.randn(1 << 19, seed=7, offset=(1 << 19) // 4)
-    assert np.array_equal(a[1 << 19:], b)       # second half drawn as its own shard: same numbers
+    assert np.array_equal(a[1 << 19:], b)       # second half drawn as its own shard: same numbers@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [
+    (1, 12, 20, 64, 64, 3), (2, 16, 16, 128, 384, 1), (2, 16, 16, 64, 32, 1), (5, 7, 3, 36, 40, 3), (1, 6, 10, 68, 96, 1),
+    (1, 4, 4, 1024, 1024, 3), (3, 2, 2, 200, 132, 3), (1, 1, 1, 16, 8, 3), (2, 32, 32, 3, 64, 3), (1, 9, 130, 72, 128, 3)])
+def test_conv_bf16_dma(ops, B, H, W, Cin, Cout, k):
+    """LDS-DMA bf16 GEMM (gemm16.hip), including the split-K atomics path (deep, few output tiles), channel tails
+    (Cin % 64 != 0, Cin = 3 padded to 8), ragged M and Cout tiles, 1x1 maps whose every tap but the centre is halo."""
+    def bf(z):
+        u = np.ascontiguousarray(z, dtype=np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=1.0 / np.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=3)
+    got = ops.conv(nhwc(x), w, b, bf16="dma")
+    close(nchw(got), O.conv2d(bf(x), bf(w), b, k // 2), 3e-5)
+
+
+@pytest.mark.gpu
+def test_conv_bf16_dma_fused_epilogue(ops):
+    """GroupNorm+GELU operand (gn_apply16) and bias + time bias + activation + mul + rowscale + residual epilogue."""
+    B, H, W, C, Co = 2, 16, 16, 64, 128
+    x = rnd(B, C, H, W, seed=4, scale=2.0) + 0.5
+    gamma, beta = rnd(C, seed=5) * 0.2 + 1, rnd(C, seed=6) * 0.1
+    w, b = rnd(Co, C, 3, 3, seed=7, scale=0.05), rnd(Co, seed=8)
+    tb, res, mul, rs = rnd(B, Co, seed=9), rnd(B, Co, H, W, seed=10), rnd(B, Co, H, W, seed=11), rnd(B, seed=12)
+    ref = O.conv2d(O.gelu(O.group_norm(x, 8, gamma, beta)), w, b, 1) + tb[:, :, None, None]
+    ref = 1 / (1 + np.exp(-ref)) * mul * rs[:, None, None, None] + res
+    sc, sh = ops.gn_scale_shift(nhwc(x), 8, gamma, beta)
+    got = ops.conv(nhwc(x), w, b, scale=sc, shift=sh, pro_act="gelu", tb=tb, epi_act="sigmoid", mul=nhwc(mul),
+                   rowscale=rs, res=nhwc(res), bf16="dma")
+    close(nchw(got), ref, 2e-2)
+
+
+
