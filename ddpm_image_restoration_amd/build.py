@@ -12,6 +12,8 @@ LIB = os.path.join(HERE, "libddpmir.so")
 SOURCES = ["igemm.hip", "gemm16.hip", "attention.hip", "attention_bf16.hip", "pointwise.hip", "sampler_kernels.hip", "jpeg_sim.hip", "model.hip", "eps_unet.hip", "api.hip", "ops_api.hip"]
 # MFMA results feed VALU (softmax) directly: keep C/D in VGPRs instead of copying through AGPRs every tile
 VGPR_MFMA = {"attention_bf16.hip", "attention.hip", "gemm16.hip"}
+# packed-f32 VALU (v_pk_add_f32) beside MFMAs costs ~3x a scalar add on gfx950: keep the softmax sums scalar
+NO_SLP = {"attention_bf16.hip"}
 NO_CONTRACT = {"sampler_kernels.hip"}   # bit-exact uint8 truncation path: no fma contraction
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -45,6 +47,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         extra = ["-ffp-contract=off"] if src in NO_CONTRACT else []
         if src in VGPR_MFMA:
             extra += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+        if src in NO_SLP:
+            extra += ["-fno-slp-vectorize"]
         cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False

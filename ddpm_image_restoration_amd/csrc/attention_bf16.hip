@@ -130,7 +130,7 @@ constexpr float RESCALE_THR = 20.0f;   // log2 units
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int D, int QS, int TS, int WPS = 0, int DMA = 1>
+template <int D, int QS, int TS, int WPS = 0, int DMA = 1, int DEN = 0>
 __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
                                                   const float* __restrict__ Kmax, float* __restrict__ out, int ldo,
                                                   int N, int NT, int heads, int nqb, int npairs,
@@ -186,6 +186,9 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
   // head_dim >= 32 has no spare accumulator row for the ones trick: the softmax denominator comes from one more
   // MFMA per k-step with an all-ones A operand (8 VALU issue cycles instead of a 16-add chain per tile)
   f32x16 osum[QS];
+  float2 lacc[QS];
+#pragma unroll
+  for (int u = 0; u < QS; ++u) lacc[u] = make_float2(0.f, 0.f);
   bf16x8 ones8;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones8[j] = (__bf16)1.0f;
@@ -288,8 +291,11 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
           for (int c = 0; c < G::KC; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[u][c], s, 0, 0, 0);
           bf16x8 pb[2];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(s[r]);
-          if (!G::ONES) {
+          for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r]); pb[r >> 3][r & 7] = (__bf16)s[r]; }
+          if (!G::ONES && DEN) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) { lacc[u].x += s[r]; lacc[u].y += s[r + 1]; }
+          } else if (!G::ONES) {
             osum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[0], osum[u], 0, 0, 0);
             osum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[1], osum[u], 0, 0, 0);
           }
@@ -354,6 +360,7 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
             if (!first) {
               const float f = exp2f(-delta);
               lsum[u] *= f;
+              lacc[u].x *= f; lacc[u].y *= f;
               if (!G::ONES) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) osum[u][r] *= f;
@@ -371,9 +378,10 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
         for (int r = 0; r < 16; ++r) {
           float p = __builtin_amdgcn_exp2f(s[r]);
           pb[r >> 3][r & 7] = (__bf16)p;
+          ps += p;
         }
-        (void)ps;
-        if (!G::ONES) {
+        if (!G::ONES && DEN) lacc[u].x += ps;
+        else if (!G::ONES) {
           osum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[0], osum[u], 0, 0, 0);
           osum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[1], osum[u], 0, 0, 0);
         }
@@ -397,6 +405,7 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
   for (int u = 0; u < QS; ++u) {
     float l;
     if (G::ONES) l = __shfl(o[u][0][(D / 8) * 4], lr);   // row D of O^T: register (D/8)*4 of lane half 0
+    else if (DEN) { l = lacc[u].x + lacc[u].y; l += __shfl_xor(l, 32); }
     else l = osum[u][0];   // every row of the ones-product holds the full sum over keys of this lane's query
     const float inv = 1.0f / l;
     const int qr = q0 + 32 * u + lr;
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
   }
 }
 
-template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT, int WPS = 0, int DMA = 1>
+template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT, int WPS = 0, int DMA = 1, int DEN = 0>
 void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* ws, hipStream_t s,
                void* out16) {
   using G = AttnGeom<D>;
@@ -442,11 +451,11 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
   const int nqb = (N + 128 * QS - 1) / (128 * QS);
   static bool attr_set = false;
   if (!attr_set) {
-    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16<D, QS, TS, WPS, DMA>),
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16<D, QS, TS, WPS, DMA, DEN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SG::STAGE_BYTES + 2 * TS * 4));
     attr_set = true;
   }
-  hipLaunchKernelGGL((flash_bf16<D, QS, TS, WPS, DMA>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
+  hipLaunchKernelGGL((flash_bf16<D, QS, TS, WPS, DMA, DEN>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
                      out, ldo, N, NT, heads, nqb, BH, reinterpret_cast<__bf16*>(out16));
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
@@ -487,6 +496,13 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
       case 22: run_flash<32, 2, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 23: run_flash<32, 2, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 24: run_flash<32, 1, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 25: run_flash<32, 1, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 26: run_flash<32, 2, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 27: run_flash<32, 1, 8, 3, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 30: run_flash<32, 2, 4, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 31: run_flash<32, 2, 16, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 28: run_flash<32, 1, 4, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 29: run_flash<32, 1, 6, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       default: break;
     }
   }
@@ -510,7 +526,7 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
     // ... and 16-tile (512-key) stages: one barrier per 32 K scores per wave (A/B: TS 4/8/16 = 8.86/7.66/7.24 ms)
     case 8: run_flash<8, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     case 16: run_flash<16, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
-    case 32: run_flash<32, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
+    case 32: run_flash<32, 2, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;   // scalar-add denominators: tools/attn_ab32.py
     case 64: run_flash<64, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     case 128: run_flash<128, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     default: throw std::runtime_error("attention_bf16: unsupported head dim");
