@@ -50,17 +50,6 @@ __global__ void pixel_shuffle2_k(const float* __restrict__ tmp, const float* __r
   }
 }
 
-__global__ void nhwc4_to_nchw3_tanh_k(const float* __restrict__ in, float* __restrict__ out, int B, int HW) {
-  const int64_t total = (int64_t)B * HW;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t b = i / HW, p = i - b * HW;
-    float4 v = *reinterpret_cast<const float4*>(in + i * 4);
-    out[(b * 3 + 0) * HW + p] = tanhf(v.x);
-    out[(b * 3 + 1) * HW + p] = tanhf(v.y);
-    out[(b * 3 + 2) * HW + p] = tanhf(v.z);
-  }
-}
-
 inline unsigned gridf(int64_t total) {
   int64_t g = (total + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -233,7 +222,7 @@ void EpsUnet::predict(const float* x, float t, float* eps, int B, int H, int W) 
   // out_conv 1x1 -> bilinear back to the input size -> tanh           conv.ipynb c0:101 (size=(32,32) there)
   run_conv(out_conv_, d1, 64, B, 2 * H, 2 * W, o4, 4, ACT_NONE);
   launch_bilinear(o4, 4, o4s, 4, B, 2 * H, 2 * W, H, W, 4, 2.0f, 2.0f, 0, 1.0f, s);
-  hipLaunchKernelGGL(nhwc4_to_nchw3_tanh_k, dim3(gridf((int64_t)B * H * W)), dim3(256), 0, s, o4s, eps, B, H * W);
+  launch_nhwc4_to_nchw3_tanh(o4s, eps, B, H, W, s);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

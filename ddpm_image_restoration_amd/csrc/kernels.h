@@ -97,6 +97,8 @@ void launch_cl_boost(const float* cl, int B, float a0, float a1, float lo, float
 
 // layout changes for the 3-channel image at the boundary
 void launch_nchw3_to_nhwc4(const float* in, float* out, int B, int H, int W, hipStream_t s);
+// [B*H*W][4] fp32 -> tanh -> [B][3][H][W]
+void launch_nhwc4_to_nchw3_tanh(const float* in, float* out, int B, int H, int W, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------ sampler
 // u8 = uint8(trunc(clamp(x*127.5+127.5, 0, 255)))  (two roundings, no fma)   webp_inference.py:509

@@ -33,6 +33,7 @@ struct ConvW {          // packed [taps][Cout][CinP] + bias
   float* w = nullptr; float* b = nullptr;
   void* w16 = nullptr;  // bf16 copy (DDPMIR_BF16 contexts)
   int cout = 0, cin = 0, cinp = 0, taps = 1;
+  int cin16 = 0, cout16 = 0;   // strides of the bf16 copy: cinp/cout, or (Cin to 8, Cout to 4) for the DMA GEMM
 };
 
 struct AvifTransformW {

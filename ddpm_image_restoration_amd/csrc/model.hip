@@ -86,10 +86,13 @@ void Context::put(Arena& a, bool upload, float*& dst, const std::string& name, s
 // torch OIHW (or [out][in] for nn.Linear) -> [tap][Cout][CinP], CinP = Cin rounded up to 4 (zeros)
 void Context::put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name, int cout, int cin, int ksz) {
   cw.cout = cout; cw.cin = cin; cw.cinp = round_up(cin, 4); cw.taps = ksz * ksz;
-  const size_t n = (size_t)cw.taps * cout * cw.cinp;
+  // the DMA GEMM wants whole 16-byte channel chunks and float4 output columns: its bf16 copy pads Cin to 8, Cout to 4
+  cw.cin16 = use_gemm16() ? round_up(cin, 8) : cw.cinp;
+  cw.cout16 = use_gemm16() ? round_up(cout, 4) : cout;
+  const size_t n = (size_t)cw.taps * cout * cw.cinp, n16 = (size_t)cw.taps * cw.cout16 * cw.cin16;
   cw.w = a.take<float>(n);
-  cw.b = a.take<float>(cout);
-  cw.w16 = cfg.dtype == DDPMIR_BF16 ? a.take<unsigned short>(n) : nullptr;
+  cw.b = a.take<float>(cw.cout16);
+  cw.w16 = cfg.dtype == DDPMIR_BF16 ? a.take<unsigned short>(n16) : nullptr;
   n_params_ += (int64_t)cout * cin * cw.taps + cout;
   if (!upload) return;
   auto iw = host_.find(name + ".weight");
@@ -106,15 +109,19 @@ void Context::put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name
       for (int t = 0; t < cw.taps; ++t) packed[((size_t)t * cout + o) * cw.cinp + c] = src[((size_t)o * cin + c) * cw.taps + t];
   DDPMIR_HIP_CHECK(hipMemcpy(cw.w, packed.data(), n * sizeof(float), hipMemcpyHostToDevice));
   if (cw.w16) {   // round-to-nearest-even bf16 copy for the matrix cores
-    std::vector<unsigned short> p16(n);
-    for (size_t i = 0; i < n; ++i) {
-      unsigned int u;
-      std::memcpy(&u, &packed[i], 4);
-      p16[i] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-    }
-    DDPMIR_HIP_CHECK(hipMemcpy(cw.w16, p16.data(), n * 2, hipMemcpyHostToDevice));
+    std::vector<unsigned short> p16(n16, 0);
+    for (int t = 0; t < cw.taps; ++t)
+      for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c) {
+          unsigned int u;
+          std::memcpy(&u, &packed[((size_t)t * cout + o) * cw.cinp + c], 4);
+          p16[((size_t)t * cw.cout16 + o) * cw.cin16 + c] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        }
+    DDPMIR_HIP_CHECK(hipMemcpy(cw.w16, p16.data(), n16 * 2, hipMemcpyHostToDevice));
   }
-  DDPMIR_HIP_CHECK(hipMemcpy(cw.b, ib->second.data.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+  std::vector<float> bias(cw.cout16, 0.f);
+  std::memcpy(bias.data(), ib->second.data.data(), cout * sizeof(float));
+  DDPMIR_HIP_CHECK(hipMemcpy(cw.b, bias.data(), cw.cout16 * sizeof(float), hipMemcpyHostToDevice));
 }
 
 void Context::layout_weights(Arena& a, bool up) {
@@ -382,6 +389,7 @@ void Context::profile_read(const std::string& cls, double* ms, int64_t* launches
 
 // ------------------------------------------------------------------------------------------------ forward
 void Context::conv(const ConvW& cw, IGemm p, hipStream_t s) {
+  if (cw.w16 && (cw.cin16 != cw.cinp || cw.cout16 != cw.cout)) throw std::logic_error("conv: bf16 copy is packed for the DMA GEMM");
   p.Wt = cw.w; p.Wt16 = cw.w16; p.bias = cw.b; p.Cout = cw.cout; p.Cin = cw.cinp; p.taps = cw.taps;
   launch_igemm(p, s);
 }
@@ -452,7 +460,7 @@ void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
 }
 
 void Context::conv16(const ConvW& cw, IGemm p, hipStream_t s) {
-  p.Wt = cw.w; p.Wt16 = cw.w16; p.bias = cw.b; p.Cout = cw.cout; p.Cin = cw.cinp; p.taps = cw.taps;
+  p.Wt = nullptr; p.Wt16 = cw.w16; p.bias = cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
   p.zero16 = plan_.zero16;
   if (gemm16_supported(p)) launch_gemm16(p, s);
   else throw std::logic_error("conv16: operand layout not supported by the DMA GEMM");
@@ -469,17 +477,12 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   IGemm g; g.B = B; g.H = H; g.W = W; g.bs = k.dct_block; g.low = k.low_size;
   // norm1 -> conv1 (+ bias + time projection)
   launch_gn_scale_shift(in, ldin, B, HW, bw.cin, gn_groups(bw.cin), bw.n1g, bw.n1b, p.gn_partial, p.sc1, p.sh1, s);
-  if (bw.cinp % 8 == 0) {
-    launch_gn_apply16(in, ldin, B, HW, bw.cin, p.sc1, p.sh1, ACT_NONE, p.a16, cin8, bw.has_shortcut ? p.x16 : nullptr,
-                      cin8, s);
-    IGemm c1 = g; c1.A16 = p.a16; c1.lda16 = cin8; c1.tb = p.tproj + bw.tproj_off; c1.ldtb = nt_total_;
-    c1.out = p.hA; c1.ldo = C;
-    conv16(bw.conv1, c1, s);
-  } else {   // 3-channel image input: register-staged kernel
-    IGemm c1 = g; c1.A = in; c1.lda = ldin; c1.scale = p.sc1; c1.shift = p.sh1;
-    c1.tb = p.tproj + bw.tproj_off; c1.ldtb = nt_total_; c1.out = p.hA; c1.ldo = C;
-    conv(bw.conv1, c1, s);
-  }
+  // (3-channel image input: x4 carries a zero 4th channel, gn_finalize zeroes its scale/shift, a16 pads to 8)
+  launch_gn_apply16(in, ldin, B, HW, bw.cinp, p.sc1, p.sh1, ACT_NONE, p.a16, cin8, bw.has_shortcut ? p.x16 : nullptr,
+                    cin8, s);
+  IGemm c1 = g; c1.A16 = p.a16; c1.lda16 = cin8; c1.tb = p.tproj + bw.tproj_off; c1.ldtb = nt_total_;
+  c1.out = p.hA; c1.ldo = C;
+  conv16(bw.conv1, c1, s);
   // norm2 -> GELU -> conv2 ; hB also as bf16 for the qkv projection
   launch_gn_scale_shift(p.hA, C, B, HW, C, gn_groups(C), bw.n2g, bw.n2b, p.gn_partial, p.sc2, p.sh2, s);
   launch_gn_apply16(p.hA, C, B, HW, C, p.sc2, p.sh2, ACT_GELU, p.a16, C, nullptr, 0, s);
@@ -517,13 +520,8 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   // shortcut + conv_out
   const float* res = in; int ldres = ldin;
   if (bw.has_shortcut) {
-    if (bw.cinp % 8 == 0) {
-      IGemm sc = g; sc.A16 = p.x16; sc.lda16 = cin8; sc.out = dest; sc.ldo = lddest;
-      conv16(bw.shortcut, sc, s);
-    } else {
-      IGemm sc = g; sc.A = in; sc.lda = ldin; sc.out = dest; sc.ldo = lddest;
-      conv(bw.shortcut, sc, s);
-    }
+    IGemm sc = g; sc.A16 = p.x16; sc.lda16 = cin8; sc.out = dest; sc.ldo = lddest;
+    conv16(bw.shortcut, sc, s);
     res = dest; ldres = lddest;
   }
   IGemm co = g; co.A16 = p.S16; co.lda16 = C; co.res = res; co.ldres = ldres; co.out = dest; co.ldo = lddest;
@@ -618,9 +616,16 @@ void Context::forward(const float* x, const float* t, const float* cl, float* ou
   else
     launch_block_transform(p.u[0], 64, p.S, 64, B, H, W, 64, k.dct_block, head_dct_, 0, 1.0f, k.head_mix, s);
   launch_gn_scale_shift(p.S, 64, B, H * W, 64, 8, head_g_, head_b_, p.gn_partial, p.sc1, p.sh1, s);
-  IGemm hc; hc.B = B; hc.H = H; hc.W = W; hc.A = p.S; hc.lda = 64; hc.scale = p.sc1; hc.shift = p.sh1;
-  hc.pro_act = ACT_SILU; hc.epi_act = ACT_TANH; hc.out = out; hc.ldo = 0; hc.store = STORE_NCHW;
-  conv(head_conv_, hc, s);
+  if (use_gemm16()) {   // SiLU(GN(.)) as a bf16 operand -> DMA GEMM with Cout padded to 4 -> tanh + NCHW in one pass
+    launch_gn_apply16(p.S, 64, B, H * W, 64, p.sc1, p.sh1, ACT_SILU, p.a16, 64, nullptr, 0, s);
+    IGemm hc; hc.B = B; hc.H = H; hc.W = W; hc.A16 = p.a16; hc.lda16 = 64; hc.out = p.x4; hc.ldo = 4;   // x4 is free again
+    conv16(head_conv_, hc, s);
+    launch_nhwc4_to_nchw3_tanh(p.x4, out, B, H, W, s);
+  } else {
+    IGemm hc; hc.B = B; hc.H = H; hc.W = W; hc.A = p.S; hc.lda = 64; hc.scale = p.sc1; hc.shift = p.sh1;
+    hc.pro_act = ACT_SILU; hc.epi_act = ACT_TANH; hc.out = out; hc.ldo = 0; hc.store = STORE_NCHW;
+    conv(head_conv_, hc, s);
+  }
   if (prof_on_) {  // close the "forward" span (the attention spans nested inside are already closed)
     for (auto it = prof_spans_.rbegin(); it != prof_spans_.rend(); ++it)
       if (it->cls == PROF_FWD) { DDPMIR_HIP_CHECK(hipEventRecord(it->b, s)); break; }

@@ -73,27 +73,32 @@ __global__ __launch_bounds__(256) void gn_partial(const float* __restrict__ x, i
   }
 }
 
-__global__ void gn_finalize(const double* __restrict__ partial, int splits, int HW, int C, int Cs, int G,
-                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                            float* __restrict__ scale, float* __restrict__ shift) {
-  const int b = blockIdx.y;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Cs) return;
-  if (c >= C) { scale[(size_t)b * Cs + c] = 0.f; shift[(size_t)b * Cs + c] = 0.f; return; }
-  const int cpg = C / G, g = c / cpg;
+// one 64-lane wave per (sample, group): strided sum of the double partials, wave reduction, then the group's
+// channels (and, from the last group, the padded channels Cs > C) get their folded scale / shift
+__global__ __launch_bounds__(64) void gn_finalize(const double* __restrict__ partial, int splits, int HW, int C, int Cs,
+                                                  int G, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* __restrict__ scale, float* __restrict__ shift) {
+  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+  const int cpg = C / G;
   double t1 = 0.0, t2 = 0.0;
-  for (int s = 0; s < splits; ++s) {
+  for (int s = lane; s < splits; s += 64) {
     const double* o = partial + (((size_t)b * splits + s) * G + g) * 2;
     t1 += o[0]; t2 += o[1];
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { t1 += __shfl_xor(t1, off); t2 += __shfl_xor(t2, off); }
   const double n = (double)HW * cpg;
   const double mean = t1 / n;
   double var = t2 / n - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-  const float sc = rstd * gamma[c];
-  scale[(size_t)b * Cs + c] = sc;
-  shift[(size_t)b * Cs + c] = beta[c] - (float)mean * sc;
+  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+    const float sc = rstd * gamma[c];
+    scale[(size_t)b * Cs + c] = sc;
+    shift[(size_t)b * Cs + c] = beta[c] - (float)mean * sc;
+  }
+  if (g == G - 1)
+    for (int c = C + lane; c < Cs; c += 64) { scale[(size_t)b * Cs + c] = 0.f; shift[(size_t)b * Cs + c] = 0.f; }
 }
 
 // ------------------------------------------------------------------------------------------- resampling
@@ -343,6 +348,17 @@ __global__ void nchw3_to_nhwc4_k(const float* __restrict__ in, float* __restrict
   }
 }
 
+__global__ void nhwc4_to_nchw3_tanh_k(const float* __restrict__ in, float* __restrict__ out, int B, int HW) {
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t b = i / HW, p = i - b * HW;
+    float4 v = *reinterpret_cast<const float4*>(in + i * 4);
+    out[(b * 3 + 0) * HW + p] = tanhf(v.x);
+    out[(b * 3 + 1) * HW + p] = tanhf(v.y);
+    out[(b * 3 + 2) * HW + p] = tanhf(v.z);
+  }
+}
+
 inline unsigned grid_for(int64_t total, int block = 256) {
   int64_t g = (total + block - 1) / block;
   if (g < 1) g = 1;
@@ -367,7 +383,7 @@ void launch_gn_scale_shift(const float* x, int ldx, int B, int HW, int C, int G,
   if (C > 1024) throw std::runtime_error("group norm: C > 1024 unsupported");
   const int splits = gn_splits(HW, C);
   hipLaunchKernelGGL(gn_partial, dim3(splits, B), dim3(256), 0, stream, x, ldx, HW, C, G, splits, partial);
-  hipLaunchKernelGGL(gn_finalize, dim3(cdiv(Cs, 128), B), dim3(128), 0, stream, partial, splits, HW, C, Cs, G,
+  hipLaunchKernelGGL(gn_finalize, dim3(G, B), dim3(64), 0, stream, partial, splits, HW, C, Cs, G,
                      gamma, beta, scale, shift);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
@@ -432,6 +448,11 @@ void launch_time_embed(const float* t, int B, const TimeEmbedW& w, float* hidden
 
 void launch_cl_boost(const float* cl, int B, float a0, float a1, float lo, float hi, float* out, hipStream_t s) {
   hipLaunchKernelGGL(cl_boost_k, dim3(cdiv(B, 64)), dim3(64), 0, s, cl, B, a0, a1, lo, hi, out);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_nhwc4_to_nchw3_tanh(const float* in, float* out, int B, int H, int W, hipStream_t s) {
+  hipLaunchKernelGGL(nhwc4_to_nchw3_tanh_k, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, s, in, out, B, H * W);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
