@@ -80,63 +80,92 @@ __global__ void randn_k(float* __restrict__ out, int64_t n, uint64_t seed, uint6
 
 // ------------------------------------------------------------------------------------------- separable DFT
 // rows:  T[p][y][v] = sum_x in[p][y][x] * w^(v*x),  w = exp(-+2 pi i / W)  (complex in optional)
-// One workgroup per (plane row y); the row sits in LDS, each thread produces output bins v = tid, tid+256...
-// Twiddles come from an n-entry table indexed by (v*x) mod n -- exact periodicity, no drift.
+// One workgroup per RB = 8 consecutive rows; the rows sit in LDS interleaved [x][8] so one x of all 8 rows is two
+// broadcast ds_read_b128 per component, and the per-lane twiddle read is shared by the 8 rows.  Each thread produces
+// output bins v = tid, tid+256...  Twiddles come from an n-entry table indexed by (v*x) mod n -- exact periodicity,
+// no drift.  The per-output summation order (x ascending, mul/mul/sub/add) is fixed: results do not depend on RB.
+constexpr int DFT_RB = 8;
 __global__ __launch_bounds__(256) void dft_rows_k(const float* __restrict__ in_re, const float* __restrict__ in_im,
                                                   float* __restrict__ out_re, float* __restrict__ out_im, int W,
-                                                  const float* __restrict__ cs, const float* __restrict__ sn,
-                                                  float sign, float scale) {
-  extern __shared__ float sh[];
-  float* xr = sh; float* xi = sh + W; float* tc = sh + 2 * W; float* ts = sh + 3 * W;
-  const size_t row = blockIdx.x;
-  for (int x = threadIdx.x; x < W; x += 256) {
-    xr[x] = in_re[row * W + x];
-    xi[x] = in_im ? in_im[row * W + x] : 0.f;
-    tc[x] = cs[x];
-    ts[x] = sign * sn[x];
+                                                  int64_t nrows, const float* __restrict__ cs,
+                                                  const float* __restrict__ sn, float sign, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  float* xr = sh; float* xi = sh + DFT_RB * W; float* tc = sh + 2 * DFT_RB * W; float* ts = tc + W;
+  const int64_t row0 = (int64_t)blockIdx.x * DFT_RB;
+  for (int i = threadIdx.x; i < DFT_RB * W; i += 256) {
+    const int r = i / W, x = i - r * W;
+    const bool ok = row0 + r < nrows;
+    xr[x * DFT_RB + r] = ok ? in_re[(row0 + r) * W + x] : 0.f;
+    xi[x * DFT_RB + r] = (ok && in_im) ? in_im[(row0 + r) * W + x] : 0.f;
   }
+  for (int x = threadIdx.x; x < W; x += 256) { tc[x] = cs[x]; ts[x] = sign * sn[x]; }
   __syncthreads();
   for (int v = threadIdx.x; v < W; v += 256) {
-    float ar = 0.f, ai = 0.f;
+    float ar[DFT_RB], ai[DFT_RB];
+#pragma unroll
+    for (int r = 0; r < DFT_RB; ++r) { ar[r] = 0.f; ai[r] = 0.f; }
     int idx = 0;
     for (int x = 0; x < W; ++x) {
-      float c = tc[idx], s = ts[idx];       // e^{i*sign*2pi*v*x/W} = c + i s
-      ar += xr[x] * c - xi[x] * s;
-      ai += xr[x] * s + xi[x] * c;
+      const float c = tc[idx], sv = ts[idx];       // e^{i*sign*2pi*v*x/W} = c + i s
+      float a[DFT_RB], b[DFT_RB];
+      *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(xr + x * DFT_RB);
+      *reinterpret_cast<float4*>(a + 4) = *reinterpret_cast<const float4*>(xr + x * DFT_RB + 4);
+      *reinterpret_cast<float4*>(b) = *reinterpret_cast<const float4*>(xi + x * DFT_RB);
+      *reinterpret_cast<float4*>(b + 4) = *reinterpret_cast<const float4*>(xi + x * DFT_RB + 4);
+#pragma unroll
+      for (int r = 0; r < DFT_RB; ++r) {
+        ar[r] += a[r] * c - b[r] * sv;
+        ai[r] += a[r] * sv + b[r] * c;
+      }
       idx += v; if (idx >= W) idx -= W;
     }
-    out_re[row * W + v] = ar * scale;
-    out_im[row * W + v] = ai * scale;
+#pragma unroll
+    for (int r = 0; r < DFT_RB; ++r)
+      if (row0 + r < nrows) {
+        out_re[(row0 + r) * W + v] = ar[r] * scale;
+        out_im[(row0 + r) * W + v] = ai[r] * scale;
+      }
   }
 }
 
-// columns: O[p][u][x] = sum_y in[p][y][x] * w^(u*y).  Workgroup = (plane p, 64-wide x strip); threads
-// (xl = tid & 63, ug = tid >> 6) loop u = ug, ug+4, ...; coalesced along x.
+// columns: O[p][u][x] = sum_y in[p][y][x] * w^(u*y).  Workgroup = (plane p, 64-wide x strip, block of 4*UB output
+// rows); lane = x (coalesced), every wave owns UB = 8 output rows u, so one pair of coalesced loads per y feeds 8
+// complex MACs and the twiddles are wave-uniform (broadcast LDS reads).  Same per-output summation order as above.
+constexpr int DFT_UB = 8;
 __global__ __launch_bounds__(256) void dft_cols_k(const float* __restrict__ in_re, const float* __restrict__ in_im,
                                                   float* __restrict__ out_re, float* __restrict__ out_im, int H, int W,
                                                   const float* __restrict__ cs, const float* __restrict__ sn,
                                                   float sign, float scale, int real_only) {
-  extern __shared__ float sh[];
+  extern __shared__ __attribute__((aligned(16))) float sh[];
   float* tc = sh; float* ts = sh + H;
   for (int y = threadIdx.x; y < H; y += 256) { tc[y] = cs[y]; ts[y] = sign * sn[y]; }
   __syncthreads();
-  const int p = blockIdx.y;
+  const int p = blockIdx.z;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  if (x >= W) return;
+  const int u0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * DFT_UB;
+  if (x >= W || u0 >= H) return;
   const float* br = in_re + (size_t)p * H * W + x;
   const float* bi = in_im + (size_t)p * H * W + x;
-  for (int u = threadIdx.x >> 6; u < H; u += 4) {
-    float ar = 0.f, ai = 0.f;
-    int idx = 0;
-    for (int y = 0; y < H; ++y) {
-      float c = tc[idx], s = ts[idx];
-      float vr = br[(size_t)y * W], vi = bi[(size_t)y * W];
-      ar += vr * c - vi * s;
-      ai += vr * s + vi * c;
-      idx += u; if (idx >= H) idx -= H;
+  float ar[DFT_UB], ai[DFT_UB];
+  int idx[DFT_UB], inc[DFT_UB];
+#pragma unroll
+  for (int j = 0; j < DFT_UB; ++j) { ar[j] = 0.f; ai[j] = 0.f; idx[j] = 0; inc[j] = u0 + j < H ? u0 + j : 0; }
+  for (int y = 0; y < H; ++y) {
+    const float vr = br[(size_t)y * W], vi = bi[(size_t)y * W];
+#pragma unroll
+    for (int j = 0; j < DFT_UB; ++j) {
+      const float c = tc[idx[j]], sv = ts[idx[j]];
+      ar[j] += vr * c - vi * sv;
+      ai[j] += vr * sv + vi * c;
+      idx[j] += inc[j]; if (idx[j] >= H) idx[j] -= H;
     }
-    out_re[((size_t)p * H + u) * W + x] = ar * scale;
-    if (!real_only) out_im[((size_t)p * H + u) * W + x] = ai * scale;
+  }
+#pragma unroll
+  for (int j = 0; j < DFT_UB; ++j) {
+    const int u = u0 + j;
+    if (u >= H) break;
+    out_re[((size_t)p * H + u) * W + x] = ar[j] * scale;
+    if (!real_only) out_im[((size_t)p * H + u) * W + x] = ai[j] * scale;
   }
 }
 
@@ -206,13 +235,24 @@ void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStre
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
+// rows wider than ~900 pixels need more than the default 64 KiB of dynamic LDS
+static void dft_rows_lds(int W) {
+  const size_t bytes = (size_t)(2 * DFT_RB + 2) * W * sizeof(float);
+  if (bytes > 160 * 1024) throw std::invalid_argument("phase_consistency: image width too large for the DFT row kernel");
+  if (bytes > 64 * 1024)
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dft_rows_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)bytes));
+}
+
 void launch_dft2_forward(const float* x, float* re, float* im, float* tmp_re, float* tmp_im, int P, const DftPlan& d,
                          hipStream_t s) {
   const int H = d.H, W = d.W;
-  hipLaunchKernelGGL(dft_rows_k, dim3((unsigned)((size_t)P * H)), dim3(256), 4 * W * sizeof(float), s, x,
-                     (const float*)nullptr, tmp_re, tmp_im, W, d.cos_w, d.sin_w, -1.0f, 1.0f);
-  hipLaunchKernelGGL(dft_cols_k, dim3(cdiv(W, 64), P), dim3(256), 2 * H * sizeof(float), s, tmp_re, tmp_im, re, im,
-                     H, W, d.cos_h, d.sin_h, -1.0f, 1.0f, 0);
+  const int64_t nrows = (int64_t)P * H;
+  dft_rows_lds(W);
+  hipLaunchKernelGGL(dft_rows_k, dim3((unsigned)cdiv64(nrows, DFT_RB)), dim3(256), (2 * DFT_RB + 2) * W * sizeof(float), s,
+                     x, (const float*)nullptr, tmp_re, tmp_im, W, nrows, d.cos_w, d.sin_w, -1.0f, 1.0f);
+  hipLaunchKernelGGL(dft_cols_k, dim3(cdiv(W, 64), cdiv(H, 4 * DFT_UB), P), dim3(256), 2 * H * sizeof(float), s, tmp_re,
+                     tmp_im, re, im, H, W, d.cos_h, d.sin_h, -1.0f, 1.0f, 0);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
@@ -228,10 +268,12 @@ void launch_phase_apply_inverse(const float* x, const float* xre, const float* x
   const int64_t n = (int64_t)P * H * W;
   hipLaunchKernelGGL(mag_times_phase_k, dim3(grid_for(n)), dim3(256), 0, s, xre, xim, ure, uim, tmp_re, tmp_im, n);
   // inverse along columns (u -> y), then rows (v -> x); 1/(H*W) split over the two passes
-  hipLaunchKernelGGL(dft_cols_k, dim3(cdiv(W, 64), P), dim3(256), 2 * H * sizeof(float), s, tmp_re, tmp_im, tmp2_re,
-                     tmp2_im, H, W, d.cos_h, d.sin_h, 1.0f, 1.0f / (float)H, 0);
-  hipLaunchKernelGGL(dft_rows_k, dim3((unsigned)((size_t)P * H)), dim3(256), 4 * W * sizeof(float), s, tmp2_re,
-                     tmp2_im, tmp_re, tmp_im, W, d.cos_w, d.sin_w, 1.0f, 1.0f / (float)W);
+  hipLaunchKernelGGL(dft_cols_k, dim3(cdiv(W, 64), cdiv(H, 4 * DFT_UB), P), dim3(256), 2 * H * sizeof(float), s, tmp_re,
+                     tmp_im, tmp2_re, tmp2_im, H, W, d.cos_h, d.sin_h, 1.0f, 1.0f / (float)H, 0);
+  const int64_t nrows = (int64_t)P * H;
+  dft_rows_lds(W);
+  hipLaunchKernelGGL(dft_rows_k, dim3((unsigned)cdiv64(nrows, DFT_RB)), dim3(256), (2 * DFT_RB + 2) * W * sizeof(float), s,
+                     tmp2_re, tmp2_im, tmp_re, tmp_im, W, nrows, d.cos_w, d.sin_w, 1.0f, 1.0f / (float)W);
   // python: alpha * x + (1 - alpha) * adjusted ; (1 - alpha) is evaluated in double by the caller
   hipLaunchKernelGGL(blend_k, dim3(grid_for(n)), dim3(256), 0, s, x, tmp_re, out, alpha, one_minus_alpha, n);
   DDPMIR_HIP_CHECK(hipGetLastError());
