@@ -447,7 +447,7 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
   const size_t kv_bytes = ((size_t)BH * NT * G::TILE_BYTES + 255) & ~size_t(255);
   float* Kmax = reinterpret_cast<float*>(KVp + kv_bytes);
   const float qscale = 1.44269504088896340736f / sqrtf((float)D);
-  hipLaunchKernelGGL(pack_qkv_bf16<D>, dim3(NT, heads, B), dim3(256), 0, s, qkv, Qp, KVp, Kmax, N, NT, C, qscale);
+  if (qkv) hipLaunchKernelGGL(pack_qkv_bf16<D>, dim3(NT, heads, B), dim3(256), 0, s, qkv, Qp, KVp, Kmax, N, NT, C, qscale);
   const int nqb = (N + 128 * QS - 1) / (128 * QS);
   static bool attr_set = false;
   if (!attr_set) {
@@ -473,6 +473,28 @@ size_t ws_bytes_for(int B, int N, int heads) {
 bool attention_bf16_supported(int N, int C, int heads) {
   const int D = C / heads;
   return (D == 8 || D == 16 || D == 32 || D == 64 || D == 128) && N >= 64;
+}
+
+static_assert(AttnGeom<16>::TILE_BYTES == ATTN16_TILE_BYTES && AttnGeom<16>::KT_BYTES == ATTN16_KT_BYTES &&
+              AttnGeom<16>::RV == ATTN16_RV && AttnGeom<16>::DP == 16, "AttnPack16 geometry out of sync");
+
+bool attention_bf16_prepack_supported(int N, int C, int heads) {
+  return C == 64 && heads == 4 && (N % 32) == 0 && N >= 64;
+}
+
+AttnPack16 attention_bf16_pack_targets(int B, int N, int C, int heads, void* ws) {   // same carve-up as run_flash<16>
+  using G = AttnGeom<16>;
+  (void)C;
+  const size_t NT = (N + 31) / 32, BH = (size_t)B * heads;
+  const size_t q_bytes = (BH * NT * 32 * G::DP * 2 + 255) & ~size_t(255);
+  const size_t kv_bytes = (BH * NT * G::TILE_BYTES + 255) & ~size_t(255);
+  AttnPack16 t;
+  t.q = ws;
+  t.kv = static_cast<unsigned char*>(ws) + q_bytes;
+  t.kmax = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + q_bytes + kv_bytes);
+  t.ntiles = (int)NT;
+  t.qscale = 1.44269504088896340736f / sqrtf(16.0f);
+  return t;
 }
 
 size_t attention_bf16_workspace(int B, int N, int C, int heads) {

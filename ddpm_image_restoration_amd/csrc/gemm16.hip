@@ -26,11 +26,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 namespace {
 
-constexpr int BM = 128, STAGES = 3;
+constexpr int BM = 128;
 
 // BK = K elements per stage (64 or 32).  BK = 32 halves the stage so three workgroups fit one CU (48 KiB each):
 // one workgroup's barrier waits, LDS-read latency and epilogue overlap the MFMAs of the other two.
-template <int NT, int BK>
+// STAGES = 3 in general; 2 when the whole K extent is at most two stages (1x1 convs with Cin <= 64: the level-0
+// projections and gates), which lets a fourth workgroup share the CU and hide the load latency these short kernels are
+// made of.
+template <int NT, int BK, int STAGES>
 __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ROWB = BK * 2;                         // bytes per LDS row
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
 
   // ------------------------------------------------------------------------------------------ epilogue
   if ((p.dbg & 8) && acc[0][0] != 12345.f) return;
-  const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE;
+  const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE || p.sel_C;
   const bool atomic = nsplit > 1;
   const bool lead = sk == 0;
   if (atomic) {
@@ -175,18 +178,96 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   constexpr int HN = NT < 2 ? NT : 2, BNH = HN * 32, BNP = BNH + 4;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                         // all waves are done reading the stage buffers
-  float* ct = reinterpret_cast<float*>(smem) + wave * 32 * BNP;
+  constexpr int CTW = (NT == 4 && 64 * 36 > 32 * BNP) ? 64 * 36 : 32 * BNP;   // floats per wave (the V^T pack pass stores its tile transposed)
+  float* ct = reinterpret_cast<float*>(smem) + wave * CTW;
   constexpr int L4 = BNH / 4, RPP = 64 / L4;
   const int c4 = lane % L4, rsub = lane / L4;
   __bf16* out16 = reinterpret_cast<__bf16*>(p.out16);
 #pragma unroll
   for (int h = 0; h < NT / HN; ++h) {
+    if constexpr (NT == 4) {
+      if (p.pk_q) {   // fused qkv projection: this 32-token x 64-column tile is Q, K or V of one 32-key attention tile
+        const int mrow0 = m0 + wave * 32, nb = n0 + h * BNH;
+        if (mrow0 >= M || nb >= 192) continue;
+        const int b = mrow0 / HW, tile = (mrow0 - b * HW) >> 5;
+        if (nb < 128) {
+          // Q / K: row-major tile [token][64 + 4], bias (and the softmax scale for Q) folded in on the way
+          const float mulv = nb == 0 ? p.pk_qscale : 1.0f;
+#pragma unroll
+          for (int q = 0; q < HN; ++q) {
+            const float bcol = p.bias[nb + q * 32 + lr];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + q * 32 + lr] = (acc[h * HN + q][r] + bcol) * mulv;
+          }
+          // lane (hh = lane >> 5, token = lane & 31) owns components 8hh..8hh+7 of every head
+          const int tok = lane & 31, hh = lane >> 5;
+#pragma unroll
+          for (int hd = 0; hd < 4; ++hd) {
+            const float* src = ct + tok * BNP + hd * 16 + hh * 8;
+            const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
+            bf16x8 v;
+            v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+            v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
+            const size_t bh_tile = (size_t)(b * 4 + hd) * p.pk_nt + tile;
+            if (nb == 0) {             // Q[bh][token][16]: 32 B per token and head
+              *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.pk_q) + (bh_tile * 32 + tok) * 16 + hh * 8) = v;
+            } else {                   // K image: lane l = hh*32 + key at byte l*16; tile max of |k| on the rounded values
+              *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(p.pk_kv) + bh_tile * ATTN16_TILE_BYTES + lane * 16) = v;
+              float nk = 0.f;
+#pragma unroll
+              for (int j2 = 0; j2 < 8; ++j2) { const float f = (float)v[j2]; nk = fmaf(f, f, nk); }
+              nk += __shfl_xor(nk, 32);
+#pragma unroll
+              for (int off = 16; off > 0; off >>= 1) nk = fmaxf(nk, __shfl_xor(nk, off));
+              if (lane == 0) p.pk_kmax[bh_tile] = sqrtf(nk) * 1.002f;
+            }
+          }
+        } else {
+          // V: TRANSPOSED tile [column][32 tokens + 4] so the 4 consecutive keys of a V^T slot group are one float4
+          constexpr int TP = 36;
+#pragma unroll
+          for (int q = 0; q < HN; ++q) {
+            const float bcol = p.bias[nb + q * 32 + lr];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+              *reinterpret_cast<float4*>(ct + (q * 32 + lr) * TP + 8 * g4 + 4 * lh) =
+                  make_float4(acc[h * HN + q][4 * g4] + bcol, acc[h * HN + q][4 * g4 + 1] + bcol,
+                              acc[h * HN + q][4 * g4 + 2] + bcol, acc[h * HN + q][4 * g4 + 3] + bcol);
+          }
+          // V^T image: slab (s, hh), row d, slot j = key (j&3) + 8*(2s + (j>>2)) + 4hh; 4 heads x 4 slabs x 16 rows = 4 per lane
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int item = it * 64 + lane, hd = item >> 6, slab = (item >> 4) & 3, row = item & 15;
+            const int sI = slab >> 1, hh = slab & 1;
+            const float* src = ct + (hd * 16 + row) * TP + 16 * sI + 4 * hh;
+            const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 8);
+            bf16x8 v;
+            v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+            v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
+            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * 4 + hd) * p.pk_nt + tile) * ATTN16_TILE_BYTES + ATTN16_KT_BYTES;
+            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * ATTN16_RV * 16 + row * 16) = v;
+          }
+          if (lane < 16) {             // the ones row (softmax denominator): row 16 of each (head, slab)
+            bf16x8 one;
+#pragma unroll
+            for (int j2 = 0; j2 < 8; ++j2) one[j2] = (__bf16)1.0f;
+            const int hd = lane >> 2, slab = lane & 3;
+            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * 4 + hd) * p.pk_nt + tile) * ATTN16_TILE_BYTES + ATTN16_KT_BYTES;
+            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * ATTN16_RV * 16 + 16 * 16) = one;
+          }
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < HN; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + q * 32 + lr] = acc[h * HN + q][r];
     const int n = n0 + h * BNH + 4 * c4;
     if (n >= p.Cout) continue;                          // Cout % 4 == 0: a float4 is all in or all out
+    const bool hi_cols = p.sel_C && n >= p.sel_C;       // sel_C % 64 == 0: a 64-column pass is all low or all high
+    const int no = hi_cols ? n - p.sel_C : n;           // column of mul / res / out
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
 #pragma unroll 4
@@ -202,22 +283,23 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
         y = rem / p.W;
         x = rem - y * p.W;
       }
+      if (p.sel_C && is_low_freq(y, x, p.H, p.W, p.bs, p.low) == hi_cols) continue;   // the other gate owns this pixel
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
       if (p.tb) { float4 t = *reinterpret_cast<const float4*>(p.tb + (size_t)b * p.ldtb + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
       if (p.epi_act != ACT_NONE) { v.x = act_apply(v.x, p.epi_act); v.y = act_apply(v.y, p.epi_act); v.z = act_apply(v.z, p.epi_act); v.w = act_apply(v.w, p.epi_act); }
-      if (p.mul) { float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + n); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
-      if (p.rowscale) { const float rs = p.rowscale[b]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+      if (p.mul) { float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + no); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+      if (p.rowscale && (!p.sel_C || hi_cols)) { const float rs = p.rowscale[b]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
       if (p.epi_mask != MASK_NONE) {
         const bool lowp = is_low_freq(y, x, p.H, p.W, p.bs, p.low);
         const bool keep = (p.epi_mask == MASK_LOW) ? lowp : !lowp;
         if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-      if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + n) = v;
+      if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + no); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + no) = v;
       if (out16) {
         bf16x4 o;
         o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(out16 + (size_t)m * p.ldo16 + n) = o;
+        *reinterpret_cast<bf16x4*>(out16 + (size_t)m * p.ldo16 + no) = o;
       }
     }
   }
@@ -271,24 +353,24 @@ __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C
   }
 }
 
-template <int NT, int BK>
+template <int NT, int BK, int STAGES>
 void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   constexpr int CPR = BK / 8;
   constexpr int BROWS = NT * 32 * CPR < 256 ? 256 / CPR : NT * 32;
   constexpr int STAGE = (BM + BROWS) * BK * 2;
   constexpr int HN = NT < 2 ? NT : 2;
-  constexpr int EPI = 4 * 32 * (HN * 32 + 4) * 4;
+  constexpr int EPI = 4 * (NT == 4 ? 64 * 36 : 32 * (HN * 32 + 4)) * 4;
   constexpr int LDS = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
   static bool attr = false;
   if (!attr) {
-    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<NT, BK>),
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<NT, BK, STAGES>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr = true;
   }
   const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
   const int nit = p.taps * cdiv(p.Cin, BK);
   int nsplit = 1;
-  const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && !p.out16 && p.out &&
+  const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && !p.out16 && p.out && !p.pk_q && !p.sel_C &&
                       (!p.res || p.res != p.out || p.ldres == p.ldo);
   if (linear && gx * gy < 256 && nit >= 8 * (64 / BK)) {
     nsplit = std::min(std::min(16, nit / (4 * (64 / BK))), cdiv(512, gx * gy));
@@ -297,7 +379,7 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   if (nsplit > 1 && !(p.res && p.res == p.out))
     hipLaunchKernelGGL(zero_rows16_k, dim3((unsigned)std::min<int64_t>(cdiv64(M * (p.Cout / 4), 256), 2048)), dim3(256), 0,
                        stream, p.out, p.ldo, M, p.Cout / 4);
-  hipLaunchKernelGGL((gemm16_kernel<NT, BK>), dim3(gx, gy, nsplit), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES>), dim3(gx, gy, nsplit), dim3(256), LDS, stream, p);
 }
 
 template <int NT>
@@ -306,8 +388,9 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
   // with few tiles go split-K, where the longer BK = 64 stage halves the barrier count (measured: DESIGN.md 4.2)
   const int64_t tiles = cdiv64(M, BM) * cdiv(p.Cout, NT * 32);
   const bool bk64 = (p.dbg & 32) ? true : (p.dbg & 64) ? false : tiles < 256;
-  if (bk64) launch_nt<NT, 64>(p, M, stream);
-  else launch_nt<NT, 32>(p, M, stream);
+  if (bk64) launch_nt<NT, 64, 3>(p, M, stream);
+  else if (p.taps * cdiv(p.Cin, 32) <= 2 && !(p.dbg & 128)) launch_nt<NT, 32, 2>(p, M, stream);
+  else launch_nt<NT, 32, 3>(p, M, stream);
 }
 
 }  // namespace
@@ -319,6 +402,11 @@ bool gemm16_supported(const IGemm& p) {
 
 void launch_gemm16(const IGemm& p, hipStream_t stream) {
   if (!gemm16_supported(p)) throw std::runtime_error("gemm16: unsupported operand layout");
+  if (p.pk_q && !(p.Cout == 192 && p.taps == 1 && p.bias && p.pk_kv && p.pk_kmax && ((p.H * p.W) % 32) == 0 &&
+                  p.pk_nt * 32 == p.H * p.W && p.epi_act == ACT_NONE && !p.mul && !p.res && !p.tb))
+    throw std::runtime_error("gemm16: fused qkv packing needs Cout = 192 (4 heads x 16), whole 32-token tiles, plain epilogue");
+  if (p.sel_C && !(p.Cout == 2 * p.sel_C && (p.sel_C % 64) == 0))
+    throw std::runtime_error("gemm16: gate selection needs Cout = 2 * sel_C with sel_C a multiple of 64");
   const int64_t M = (int64_t)p.B * p.H * p.W;
   if (M <= 0 || p.Cout <= 0) return;
   if (p.Cout <= 32) launch_bk<1>(p, M, stream);

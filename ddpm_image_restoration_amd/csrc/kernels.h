@@ -34,6 +34,13 @@ struct IGemm {
   const void* A16 = nullptr; int lda16 = 0;
   const void* zero16 = nullptr;               // >= 16 bytes of zeros in device memory (halo / tail source)
   void* out16 = nullptr; int ldo16 = 0;       // optional bf16 copy of the epilogue result (out may then be null)
+  // qkv projection fused with the attention operand packing (head_dim 16, 4 heads, C = 64: gemm16.hip epilogue writes
+  // the Q / K / V^T images of attention_bf16.hip directly instead of an fp32 [M][192] tensor); see AttnPack16
+  // per-pixel gate selection (frequency block, gemm16.hip): Cout = 2*sel_C; columns [0, sel_C) are the low-frequency gate,
+  // [sel_C, 2 sel_C) the high-frequency gate; a row only stores the half that matches its pixel class, at column n mod sel_C
+  // (mul / res / out / out16 are indexed with that column; rowscale applies to the high half only)
+  int sel_C = 0;
+  void* pk_q = nullptr; void* pk_kv = nullptr; float* pk_kmax = nullptr; int pk_nt = 0; float pk_qscale = 0.f;
   int dbg = 0;   // timing experiments only: 1 skip A loads, 2 skip B loads, 4 skip MFMA, 8 skip stores, 16 skip LDS writes
 };
 void launch_igemm(const IGemm& p, hipStream_t stream);
@@ -51,8 +58,15 @@ void launch_attention(const float* qkv, float* out, int ldo, int B, int N, int C
 // bf16 matrix-core variant (attention_bf16.hip): qkv/out stay fp32 in HBM, Q/K/V are repacked to bf16 operand
 // images in `workspace` (attention_bf16_workspace() bytes), softmax statistics and accumulators are fp32.
 bool attention_bf16_supported(int N, int C, int heads);
+// Operand images of the head_dim-16 attention kernel inside `workspace`, for producers that write them directly
+// (the fused qkv projection).  Tile = 32 keys: K image 1024 B + V^T image (2 x 2 slabs of 17 rows x 16 B).
+constexpr int ATTN16_KT_BYTES = 1024, ATTN16_RV = 17, ATTN16_TILE_BYTES = ATTN16_KT_BYTES + 4 * ATTN16_RV * 16;
+struct AttnPack16 { void* q; void* kv; float* kmax; int ntiles; float qscale; };
+bool attention_bf16_prepack_supported(int N, int C, int heads);
+AttnPack16 attention_bf16_pack_targets(int B, int N, int C, int heads, void* workspace);
 size_t attention_bf16_workspace(int B, int N, int C, int heads);
 // out16 != nullptr: the result is written as bf16 [B][N][C] there instead of fp32 `out`
+// qkv == nullptr: the operand images in `workspace` were already written by the producer (AttnPack16)
 void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* workspace,
                            hipStream_t stream, void* out16 = nullptr);
 

@@ -51,6 +51,7 @@ struct BlockW {
   // WebP / JPEG frequency block
   float* dct = nullptr;
   ConvW low0, low2, high0, high2;
+  ConvW fg1, fg2;   // DMA-GEMM path: both gates stacked (C -> [low hid | high hid]) and block-diagonal ([hid] -> [low | high])
   // AVIF frequency block
   AvifTransformW at;
   ConvW ms1[4], ms3[4], cc0, cc2, ep0, ep2;
@@ -101,6 +102,7 @@ class Context {
   void layout_weights(Arena& a, bool upload);
   void put(Arena& a, bool upload, float*& dst, const std::string& name, size_t expect);
   void put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name, int cout, int cin, int ksz);
+  void put_gate_pair(Arena& a, bool upload, BlockW& b, const std::string& fg);
 
   // ---- workspace (planned per (B,H,W))
   struct Plan {

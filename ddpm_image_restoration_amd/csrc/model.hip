@@ -124,6 +124,56 @@ void Context::put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name
   DDPMIR_HIP_CHECK(hipMemcpy(cw.b, bias.data(), cw.cout16 * sizeof(float), hipMemcpyHostToDevice));
 }
 
+// Frequency gates for the DMA GEMM: the low and the high gate (each C -> C/2 -> C, webp_inference.py:214-227) act on
+// complementary pixel sets, so both first layers are stacked into one [C][C] GEMM on the unmasked DCT tensor and both
+// second layers into one block-diagonal [2C][C] GEMM whose epilogue keeps, per pixel, the half that owns it.
+void Context::put_gate_pair(Arena& a, bool upload, BlockW& b, const std::string& fg) {
+  const int C = b.cout, Hd = C / 2;
+  auto init = [&](ConvW& cw, int cout, int cin) {
+    cw.cout = cw.cout16 = cout; cw.cin = cw.cinp = cw.cin16 = cin; cw.taps = 1;
+    cw.w = nullptr;
+    cw.b = a.take<float>(cout);
+    cw.w16 = a.take<unsigned short>((size_t)cout * cin);
+  };
+  init(b.fg1, C, C);
+  init(b.fg2, 2 * C, C);
+  if (!upload) return;
+  auto get = [&](const std::string& n, int64_t numel) -> const float* {
+    auto it = host_.find(n);
+    if (it == host_.end()) throw std::runtime_error("missing tensor in state dict: " + n);
+    if (it->second.numel() != numel) throw std::runtime_error("shape mismatch for " + n);
+    return it->second.data.data();
+  };
+  const float* wl0 = get(fg + ".low_freq_attn.0.weight", (int64_t)Hd * C);
+  const float* wh0 = get(fg + ".high_freq_attn.0.weight", (int64_t)Hd * C);
+  const float* wl2 = get(fg + ".low_freq_attn.2.weight", (int64_t)C * Hd);
+  const float* wh2 = get(fg + ".high_freq_attn.2.weight", (int64_t)C * Hd);
+  const float* bl0 = get(fg + ".low_freq_attn.0.bias", Hd);
+  const float* bh0 = get(fg + ".high_freq_attn.0.bias", Hd);
+  const float* bl2 = get(fg + ".low_freq_attn.2.bias", C);
+  const float* bh2 = get(fg + ".high_freq_attn.2.bias", C);
+  auto bf = [](float f) {
+    unsigned int u;
+    std::memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+  };
+  std::vector<unsigned short> w1((size_t)C * C), w2((size_t)2 * C * C, 0);
+  std::vector<float> b1(C), b2v(2 * C);
+  for (int o = 0; o < Hd; ++o)
+    for (int c = 0; c < C; ++c) { w1[(size_t)o * C + c] = bf(wl0[(size_t)o * C + c]); w1[(size_t)(Hd + o) * C + c] = bf(wh0[(size_t)o * C + c]); }
+  for (int o = 0; o < Hd; ++o) { b1[o] = bl0[o]; b1[Hd + o] = bh0[o]; }
+  for (int o = 0; o < C; ++o)
+    for (int c = 0; c < Hd; ++c) {
+      w2[(size_t)o * C + c] = bf(wl2[(size_t)o * Hd + c]);                 // low gate reads hidden [0, C/2)
+      w2[(size_t)(C + o) * C + Hd + c] = bf(wh2[(size_t)o * Hd + c]);      // high gate reads hidden [C/2, C)
+    }
+  for (int o = 0; o < C; ++o) { b2v[o] = bl2[o]; b2v[C + o] = bh2[o]; }
+  DDPMIR_HIP_CHECK(hipMemcpy(b.fg1.w16, w1.data(), w1.size() * 2, hipMemcpyHostToDevice));
+  DDPMIR_HIP_CHECK(hipMemcpy(b.fg2.w16, w2.data(), w2.size() * 2, hipMemcpyHostToDevice));
+  DDPMIR_HIP_CHECK(hipMemcpy(b.fg1.b, b1.data(), b1.size() * 4, hipMemcpyHostToDevice));
+  DDPMIR_HIP_CHECK(hipMemcpy(b.fg2.b, b2v.data(), b2v.size() * 4, hipMemcpyHostToDevice));
+}
+
 void Context::layout_weights(Arena& a, bool up) {
   n_params_ = 0;
   blocks_.assign(13, BlockW());
@@ -187,6 +237,7 @@ void Context::layout_weights(Arena& a, bool up) {
       put_conv(a, up, b.low2, fg + ".low_freq_attn.2", d.cout, d.cout / 2, 1);
       put_conv(a, up, b.high0, fg + ".high_freq_attn.0", d.cout / 2, d.cout, 1);
       put_conv(a, up, b.high2, fg + ".high_freq_attn.2", d.cout, d.cout / 2, 1);
+      if (use_gemm16()) put_gate_pair(a, up, b, fg);
     }
     put_conv(a, up, b.conv_out, fg + ".conv_out", d.cout, d.cout, 3);
     if (b.has_shortcut) put_conv(a, up, b.shortcut, n + ".shortcut", d.cout, d.cin, 1);
@@ -491,12 +542,21 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   if (attn) { c2.out16 = p.hB16; c2.ldo16 = C; }
   conv16(bw.conv2, c2, s);
   if (attn) {
-    IGemm q = g; q.A16 = p.hB16; q.lda16 = C; q.out = p.qkv; q.ldo = 3 * C;
+    // head_dim 16 levels: the projection's epilogue writes the attention operand images itself (no fp32 qkv round trip)
+    static const bool no_fuse = getenv("DDPMIR_NO_QKV_FUSE") != nullptr;
+    const bool prepack = !no_fuse && attention_bf16_prepack_supported(HW, C, k.heads);
+    IGemm q = g; q.A16 = p.hB16; q.lda16 = C;
+    if (prepack) {
+      const AttnPack16 t = attention_bf16_pack_targets(B, HW, C, k.heads, p.attn_ws);
+      q.pk_q = t.q; q.pk_kv = t.kv; q.pk_kmax = t.kmax; q.pk_nt = t.ntiles; q.pk_qscale = t.qscale;
+    } else {
+      q.out = p.qkv; q.ldo = 3 * C;
+    }
     conv16(bw.in_proj, q, s);
     const double nn = (double)HW;
     prof_begin(bw.level == 0 ? PROF_ATTN_L0 : PROF_ATTN, 4.0 * nn * nn * C * B, s);
     if (attention_bf16_supported(HW, C, k.heads)) {
-      launch_attention_bf16(p.qkv, p.att, C, B, HW, C, k.heads, p.attn_ws, s, p.att16);
+      launch_attention_bf16(prepack ? nullptr : p.qkv, p.att, C, B, HW, C, k.heads, p.attn_ws, s, p.att16);
     } else {
       launch_attention(p.qkv, p.att, C, B, HW, C, k.heads, s);
       launch_gn_apply16(p.att, C, B, HW, C, nullptr, nullptr, ACT_NONE, p.att16, C, nullptr, 0, s);
@@ -506,17 +566,27 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
     conv16(bw.out_proj, o, s);
   }
   // frequency block: DCT -> masked bf16 operands -> gates -> S (bf16 only, it feeds conv_out alone)
-  launch_block_transform(p.hB, C, p.xd, C, B, H, W, C, k.dct_block, bw.dct, 0, 0.f, 1.f, s, p.xdl16, p.xdh16, k.low_size);
-  IGemm a = g; a.A16 = p.xdl16; a.lda16 = C; a.epi_act = ACT_LRELU; a.out16 = p.hid16; a.ldo16 = C / 2;
-  conv16(bw.low0, a, s);
-  IGemm b2 = g; b2.A16 = p.hid16; b2.lda16 = C / 2; b2.epi_act = ACT_SIGMOID; b2.mul = p.xd; b2.ldmul = C;
-  b2.epi_mask = MASK_LOW; b2.res = p.hB; b2.ldres = C; b2.out = p.S; b2.ldo = C;
-  conv16(bw.low2, b2, s);
-  IGemm c = a; c.A16 = p.xdh16;
-  conv16(bw.high0, c, s);
-  IGemm d = b2; d.epi_mask = MASK_HIGH; d.rowscale = p.boost; d.res = p.S; d.ldres = C; d.out = nullptr;
-  d.out16 = p.S16; d.ldo16 = C;
-  conv16(bw.high2, d, s);
+  static const bool split_gates = getenv("DDPMIR_SPLIT_GATES") != nullptr;   // A/B: the four separate gate GEMMs
+  if (!split_gates) {
+    launch_block_transform(p.hB, C, p.xd, C, B, H, W, C, k.dct_block, bw.dct, 0, 0.f, 1.f, s, p.xdl16, nullptr, k.low_size);
+    IGemm a = g; a.A16 = p.xdl16; a.lda16 = C; a.epi_act = ACT_LRELU; a.out16 = p.hid16; a.ldo16 = C;
+    conv16(bw.fg1, a, s);
+    IGemm d = g; d.A16 = p.hid16; d.lda16 = C; d.epi_act = ACT_SIGMOID; d.mul = p.xd; d.ldmul = C; d.sel_C = C;
+    d.rowscale = p.boost; d.res = p.hB; d.ldres = C; d.out16 = p.S16; d.ldo16 = C;
+    conv16(bw.fg2, d, s);
+  } else {
+    launch_block_transform(p.hB, C, p.xd, C, B, H, W, C, k.dct_block, bw.dct, 0, 0.f, 1.f, s, p.xdl16, p.xdh16, k.low_size);
+    IGemm a = g; a.A16 = p.xdl16; a.lda16 = C; a.epi_act = ACT_LRELU; a.out16 = p.hid16; a.ldo16 = C / 2;
+    conv16(bw.low0, a, s);
+    IGemm b2 = g; b2.A16 = p.hid16; b2.lda16 = C / 2; b2.epi_act = ACT_SIGMOID; b2.mul = p.xd; b2.ldmul = C;
+    b2.epi_mask = MASK_LOW; b2.res = p.hB; b2.ldres = C; b2.out = p.S; b2.ldo = C;
+    conv16(bw.low2, b2, s);
+    IGemm c = a; c.A16 = p.xdh16;
+    conv16(bw.high0, c, s);
+    IGemm d = b2; d.epi_mask = MASK_HIGH; d.rowscale = p.boost; d.res = p.S; d.ldres = C; d.out = nullptr;
+    d.out16 = p.S16; d.ldo16 = C;
+    conv16(bw.high2, d, s);
+  }
   // shortcut + conv_out
   const float* res = in; int ldres = ldin;
   if (bw.has_shortcut) {

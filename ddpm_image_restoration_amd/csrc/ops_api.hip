@@ -13,6 +13,7 @@ using namespace ddpmir;
 namespace {
 thread_local std::string g_err;
 thread_local int g_bf16 = 0;
+thread_local int g_sel = 0;
 
 struct Dev {
   std::vector<void*> ptrs;
@@ -55,6 +56,7 @@ extern "C" {
 
 const char* ddpmir_ops_last_error(void) { return g_err.c_str(); }
 void ddpmir_op_set_bf16(int enable) { g_bf16 = enable; }
+void ddpmir_op_set_gate_select(int C) { g_sel = C; }
 
 int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
                    int ksize, const float* scale, const float* shift, int pro_act, int pro_mask, int bs, int low,
@@ -97,12 +99,15 @@ int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_
       p.B = B; p.H = H; p.W = W; p.Cin = cin8; p.Cout = Cout; p.taps = taps; p.bias = d.up(bias, Cout);
       p.A16 = a16; p.lda16 = cin8; p.Wt16 = d.up(w8.data(), w8.size()); p.zero16 = d.alloc<unsigned char>(256);
       p.tb = d.up(tb, (size_t)B * Cout); p.ldtb = Cout; p.epi_act = epi_act; p.bs = bs; p.low = low;
-      p.mul = d.up(mul, M * Cout); p.ldmul = Cout; p.rowscale = d.up(rowscale, B); p.epi_mask = epi_mask;
-      p.res = d.up(res, M * Cout); p.ldres = Cout;
-      float* o = d.alloc<float>(M * Cout);
-      p.out = o; p.ldo = Cout; p.store = STORE_NHWC;
+      // gate-select mode: mul / res / out have Cout/2 columns (see IGemm::sel_C)
+      const int Co = g_sel ? g_sel : Cout;
+      p.sel_C = g_sel;
+      p.mul = d.up(mul, M * Co); p.ldmul = Co; p.rowscale = d.up(rowscale, B); p.epi_mask = epi_mask;
+      p.res = d.up(res, M * Co); p.ldres = Co;
+      float* o = d.alloc<float>(M * Co);
+      p.out = o; p.ldo = Co; p.store = STORE_NHWC;
       launch_gemm16(p, nullptr);
-      d.down(out, o, M * Cout);
+      d.down(out, o, M * Co);
       return;
     }
     IGemm p;
@@ -184,6 +189,41 @@ int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int b
     DDPMIR_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
     *ms_per_call = ms / iters;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  });
+}
+
+int ddpmir_op_qkv_attention_bf16(const float* x, int B, int N, int C, int heads, const float* w_in, const float* b_in,
+                                 int fused, float* out) {
+  return guarded([&] {
+    if (C % 8 || !attention_bf16_supported(N, C, heads)) throw std::runtime_error("qkv_attention: unsupported shape");
+    if (fused && !attention_bf16_prepack_supported(N, C, heads)) throw std::runtime_error("qkv_attention: shape cannot be fused");
+    Dev d;
+    const size_t M = (size_t)B * N;
+    std::vector<unsigned short> w16((size_t)3 * C * C);
+    for (size_t i = 0; i < w16.size(); ++i) {
+      unsigned int u;
+      memcpy(&u, &w_in[i], 4);
+      w16[i] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    }
+    float* dx = d.up(x, M * C);
+    unsigned short* a16 = d.alloc<unsigned short>(M * C + 8);
+    launch_gn_apply16(dx, C, B, N, C, nullptr, nullptr, ACT_NONE, a16, C, nullptr, 0, nullptr);
+    void* ws = d.alloc<unsigned char>(attention_bf16_workspace(B, N, C, heads));
+    IGemm p;
+    p.B = B; p.H = 1; p.W = N; p.Cin = C; p.Cout = 3 * C; p.taps = 1; p.bias = d.up(b_in, (size_t)3 * C);
+    p.A16 = a16; p.lda16 = C; p.Wt16 = d.up(w16.data(), w16.size()); p.zero16 = d.alloc<unsigned char>(256);
+    float* qkv = nullptr;
+    if (fused) {
+      const AttnPack16 t = attention_bf16_pack_targets(B, N, C, heads, ws);
+      p.pk_q = t.q; p.pk_kv = t.kv; p.pk_kmax = t.kmax; p.pk_nt = t.ntiles; p.pk_qscale = t.qscale;
+    } else {
+      qkv = d.alloc<float>(M * 3 * C);
+      p.out = qkv; p.ldo = 3 * C;
+    }
+    launch_gemm16(p, nullptr);
+    float* o = d.alloc<float>(M * C);
+    launch_attention_bf16(qkv, o, C, B, N, C, heads, ws, nullptr);
+    d.down(out, o, M * C);
   });
 }
 

@@ -73,6 +73,38 @@ __global__ __launch_bounds__(256) void gn_partial(const float* __restrict__ x, i
   }
 }
 
+// Wide groups (>= 32 channels = 128 contiguous bytes per pixel, levels 2-5): one workgroup per (sample, split, GROUP),
+// so the deep levels with 64..1024 pixels still spread over G times more workgroups and the fold is a plain block
+// reduction.  Same partial layout as gn_partial.
+__global__ __launch_bounds__(256) void gn_partial_group(const float* __restrict__ x, int ldx, int HW, int C, int G,
+                                                        int splits, double* __restrict__ partial) {
+  __shared__ double r1[4], r2[4];
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x % G, sp = blockIdx.x / G, b = blockIdx.y;
+  const int cpg = C / G, lpp = cpg / 4;                 // lanes per pixel (8..256)
+  const int ppi = 256 / lpp;                            // pixels per iteration
+  const int slot = tid % lpp, pslot = tid / lpp;
+  const int64_t p_begin = (int64_t)sp * HW / splits, p_end = (int64_t)(sp + 1) * HW / splits;
+  double a1 = 0.0, a2 = 0.0;
+  if (pslot < ppi) {
+    const float* xb = x + (size_t)b * HW * ldx + g * cpg + slot * 4;
+    for (int64_t p = p_begin + pslot; p < p_end; p += ppi) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + p * ldx);
+      a1 += (double)((v.x + v.y) + (v.z + v.w));
+      a2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); }
+  if ((tid & 63) == 0) { r1[tid >> 6] = a1; r2[tid >> 6] = a2; }
+  __syncthreads();
+  if (tid == 0) {
+    double* o = partial + (((size_t)b * splits + sp) * G + g) * 2;
+    o[0] = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+    o[1] = (r2[0] + r2[1]) + (r2[2] + r2[3]);
+  }
+}
+
 // one 64-lane wave per (sample, group): strided sum of the double partials, wave reduction, then the group's
 // channels (and, from the last group, the padded channels Cs > C) get their folded scale / shift
 __global__ __launch_bounds__(64) void gn_finalize(const double* __restrict__ partial, int splits, int HW, int C, int Cs,
@@ -248,7 +280,9 @@ __global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_k(const f
           const size_t o = (((size_t)b * H + y) * W + x);
           const float val = mix_in * X[u][v] + mix_t * a;
           out[o * ldo + c] = val;
-          if (low16) {   // pre-masked bf16 operands of the low / high frequency gate GEMMs
+          if (low16 && !high16) {   // one unmasked bf16 copy: operand of the fused low/high gate GEMM
+            low16[o * C + c] = (__bf16)val;
+          } else if (low16) {       // pre-masked bf16 operands of the separate low / high frequency gate GEMMs
             const bool lowp = is_low_freq(y, x, H, W, BS, low);
             low16[o * C + c] = (__bf16)(lowp ? val : 0.f);
             high16[o * C + c] = (__bf16)(lowp ? 0.f : val);
@@ -368,9 +402,10 @@ inline unsigned grid_for(int64_t total, int block = 256) {
 
 }  // namespace
 
+// upper bound of the number of splits any launch uses (sizes the partial buffer: B * G * splits * 2 doubles)
 int gn_splits(int HW, int C) {
   (void)C;
-  int s = cdiv(HW, GN_PIX_PER_SPLIT);
+  int s = cdiv(HW, 64);
   if (s < 1) s = 1;
   if (s > GN_MAX_SPLITS) s = GN_MAX_SPLITS;
   return s;
@@ -381,8 +416,14 @@ void launch_gn_scale_shift(const float* x, int ldx, int B, int HW, int C, int G,
   // scale/shift rows are padded to a multiple of 4 channels (zeros) so igemm can read float4
   const int Cs = round_up(C, 4);
   if (C > 1024) throw std::runtime_error("group norm: C > 1024 unsupported");
-  const int splits = gn_splits(HW, C);
-  hipLaunchKernelGGL(gn_partial, dim3(splits, B), dim3(256), 0, stream, x, ldx, HW, C, G, splits, partial);
+  const int cpg = C / G;
+  const bool by_group = cpg >= 32 && (cpg % 4) == 0 && cpg <= 1024 && (ldx % 4) == 0;
+  int splits = cdiv(HW, by_group ? 64 : GN_PIX_PER_SPLIT);
+  splits = splits < 1 ? 1 : (splits > GN_MAX_SPLITS ? GN_MAX_SPLITS : splits);
+  if (by_group)
+    hipLaunchKernelGGL(gn_partial_group, dim3(G * splits, B), dim3(256), 0, stream, x, ldx, HW, C, G, splits, partial);
+  else
+    hipLaunchKernelGGL(gn_partial, dim3(splits, B), dim3(256), 0, stream, x, ldx, HW, C, G, splits, partial);
   hipLaunchKernelGGL(gn_finalize, dim3(G, B), dim3(64), 0, stream, partial, splits, HW, C, Cs, G,
                      gamma, beta, scale, shift);
   DDPMIR_HIP_CHECK(hipGetLastError());

@@ -14,10 +14,12 @@ _sigs = {
     "ddpmir_op_conv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int,
                                  C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P]),
     "ddpmir_op_set_bf16": (None, [C.c_int]),
+    "ddpmir_op_set_gate_select": (None, [C.c_int]),
     "ddpmir_op_conv_time": (C.c_int, [C.c_int] * 11 + [C.POINTER(C.c_float)]),
     "ddpmir_op_gn_scale_shift": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "ddpmir_op_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ddpmir_op_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ddpmir_op_qkv_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "ddpmir_op_attention_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ddpmir_op_block_transform": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float,
                                             C.c_float, _P]),
@@ -64,8 +66,9 @@ MASK = {None: 0, "none": 0, "low": 1, "high": 2}
 
 
 def conv(x, w, bias=None, scale=None, shift=None, pro_act=None, pro_mask=None, bs=4, low=3, tb=None, epi_act=None,
-         mul=None, rowscale=None, epi_mask=None, res=None, nchw_out=False, bf16=False):
+         mul=None, rowscale=None, epi_mask=None, res=None, nchw_out=False, bf16=False, gate_select=0):
     lib = _lib_ops()
+    lib.ddpmir_op_set_gate_select(int(gate_select))
     lib.ddpmir_op_set_bf16(2 if bf16 == "dma" else int(bf16))
     x, w = _f(x), _f(w)
     if w.ndim == 2:
@@ -73,7 +76,8 @@ def conv(x, w, bias=None, scale=None, shift=None, pro_act=None, pro_mask=None, b
     b, h, wd, cin = x.shape
     cout, _, k, _ = w.shape
     bias, scale, shift, tb, mul, rowscale, res = map(_f, (bias, scale, shift, tb, mul, rowscale, res))
-    out = np.empty((b, cout, h, wd) if nchw_out else (b, h, wd, cout), dtype=np.float32)
+    co = gate_select if gate_select else cout
+    out = np.empty((b, co, h, wd) if nchw_out else (b, h, wd, co), dtype=np.float32)
     rc = lib.ddpmir_op_conv(_p(x), b, h, wd, cin, _p(w), _p(bias), cout, k, _p(scale), _p(shift), ACT[pro_act],
                             MASK[pro_mask], bs, low, _p(tb), ACT[epi_act], _p(mul), _p(rowscale), MASK[epi_mask],
                             _p(res), int(nchw_out), _p(out))
@@ -108,6 +112,16 @@ def attention(qkv, heads, bf16=False):
     out = np.empty((b, n, c3 // 3), np.float32)
     fn = lib.ddpmir_op_attention_bf16 if bf16 else lib.ddpmir_op_attention
     _chk(lib, fn(_p(qkv), b, n, c3 // 3, heads, _p(out)), "op_attention")
+    return out
+
+
+def qkv_attention_bf16(x, w_in, b_in, heads, fused=True):
+    """x [B,N,C] -> softmax(QK^T/sqrt(d))V per head, [B,N,C]; in_proj fused with the operand packing or not."""
+    lib = _lib_ops()
+    x, w_in, b_in = _f(x), _f(w_in), _f(b_in)
+    b, n, c = x.shape
+    out = np.empty((b, n, c), np.float32)
+    _chk(lib, lib.ddpmir_op_qkv_attention_bf16(_p(x), b, n, c, heads, _p(w_in), _p(b_in), int(fused), _p(out)), "op_qkv_attention")
     return out
 
 

@@ -24,6 +24,10 @@ int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_
                    const float* res, int nchw_out, float* out);
 /* select the bf16 matrix-core variant for subsequent ddpmir_op_conv calls of this thread (0 = fp32) */
 void ddpmir_op_set_bf16(int enable);
+/* gate-select epilogue of the DMA GEMM for subsequent ddpmir_op_conv calls (0 = off): Cout = 2C; per pixel only the
+ * low-frequency half [0,C) or the high-frequency half [C,2C) is kept (webp_inference.py:241-252 masks), so mul / res /
+ * out are [B,H,W,C] and rowscale multiplies the high half only */
+void ddpmir_op_set_gate_select(int C);
 /* device-resident timing of one conv/linear launch on random data (ms per call); gelu_norm adds the fused
  * GroupNorm+GELU prologue; dbg is a kernel-internal experiment mask (0 in normal use) */
 int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int bf16, int gelu_norm, int residual,
@@ -37,6 +41,11 @@ int ddpmir_op_gn_scale_shift(const float* x, int B, int HW, int C, int G, const 
 int ddpmir_op_attention(const float* qkv, int B, int N, int C, int heads, float* out);
 /* same through the bf16 matrix-core kernel (fp32 in/out, bf16 operands, fp32 accumulation) */
 int ddpmir_op_attention_bf16(const float* qkv, int B, int N, int C, int heads, float* out);
+/* qkv projection (nn.MultiheadAttention in_proj, webp_inference.py:295) + attention core through the bf16 path:
+ * x [B,N,C] -> out [B,N,C] (before out_proj).  fused = 1: the projection's epilogue writes the attention operand
+ * images directly (head_dim 16, 4 heads, N % 32 == 0); fused = 0: fp32 qkv tensor + separate packing kernel. */
+int ddpmir_op_qkv_attention_bf16(const float* x, int B, int N, int C, int heads, const float* w_in, const float* b_in,
+                                 int fused, float* out);
 /* device-resident timing of the attention kernels on random data: mode 0 = fp32, 1 = bf16; average ms per call */
 int ddpmir_op_attention_time(int B, int N, int C, int heads, int mode, int iters, float* ms_per_call);
 

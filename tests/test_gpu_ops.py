@@ -63,6 +63,28 @@ def test_conv_bf16(ops, B, H, W, Cin, Cout, k):
     close(nchw(got), O.conv2d(x, w, b, k // 2), 2e-2)
 
 
+@pytest.mark.parametrize("H,W,bs,low", [(16, 16, 4, 3), (24, 40, 8, 4), (2, 2, 8, 4), (5, 13, 4, 3)])
+def test_conv_bf16_dma_gate_select(ops, H, W, bs, low):
+    """frequency gates as one block-diagonal GEMM: per pixel keep sigmoid(low half) or boost * sigmoid(high half)
+    according to the static in-block mask (webp_inference.py:241-252), times the DCT tensor, plus the residual."""
+    B, C = 2, 64
+    hid = rnd(B, C, H, W, seed=20)
+    w = rnd(2 * C, C, 1, 1, seed=21, scale=0.2)
+    w[:C, C // 2:] = 0; w[C:, :C // 2] = 0            # block diagonal: low gate reads hidden[:C/2], high gate the rest
+    b = rnd(2 * C, seed=22, scale=0.3)
+    xd, hb, boost = rnd(B, C, H, W, seed=23), rnd(B, C, H, W, seed=24), np.abs(rnd(B, seed=25)) + 0.5
+    got = ops.conv(nhwc(hid), w, b, bs=bs, low=low, epi_act="sigmoid", mul=nhwc(xd), rowscale=boost, res=nhwc(hb),
+                   bf16="dma", gate_select=C)
+    def bf(z):
+        u = np.ascontiguousarray(z, dtype=np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    z = O.conv2d(bf(hid), bf(w), b, 0)
+    sig = 1 / (1 + np.exp(-z.astype(np.float64)))
+    m = O.low_mask(H, W, bs, low)[None, None]
+    ref = hb + xd * np.where(m > 0, sig[:, :C], sig[:, C:] * boost[:, None, None, None])
+    close(nchw(got), ref.astype(np.float32), 2e-5)
+
+
 def test_conv_bf16_fused_prologue_epilogue(ops):
     B, H, W, C, Co = 2, 16, 16, 64, 128
     x = rnd(B, C, H, W, seed=4, scale=2.0) + 0.5
@@ -172,6 +194,33 @@ def test_attention_bf16(ops, N, C, heads):
     err = np.abs(got - ref).max()
     assert err < 8e-2, err            # bf16 operands: 2^-8 relative on q, k, v, p
     assert np.abs(got - ref).mean() < 4e-3
+
+
+@pytest.mark.parametrize("B,N", [(2, 256), (1, 4096), (3, 96 * 32), (5, 64)])
+def test_qkv_projection_fused_with_attention_packing(ops, B, N):
+    """in_proj whose epilogue writes the attention operand images (Q / K / V^T tiles, |k| bounds) must give exactly
+    what the separate fp32-qkv + pack_qkv path gives (same GEMM, same roundings), and match nn.MultiheadAttention's
+    core (webp_inference.py:317-321) within bf16 operand precision."""
+    C, heads = 64, 4
+    x = rnd(B, N, C, seed=60, scale=1.2)
+    w = rnd(3 * C, C, seed=61, scale=1.0 / np.sqrt(C)) * 1.5
+    b = rnd(3 * C, seed=62, scale=0.3)
+    fused = ops.qkv_attention_bf16(x, w, b, heads, fused=True)
+    plain = ops.qkv_attention_bf16(x, w, b, heads, fused=False)
+    dd = np.abs(fused - plain)
+    assert np.array_equal(fused, plain), (dd.max(), int((dd > 0).sum()), np.argwhere(dd > 0)[:6].tolist())
+    def bf(z):   # the GEMM consumes bf16-rounded x and W (exact products, fp32 accumulation)
+        u = np.ascontiguousarray(z, dtype=np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    qkv = (bf(x).astype(np.float64) @ bf(w).T.astype(np.float64) + b).astype(np.float32)
+    d = C // heads
+    sp = lambda z: z.reshape(B, N, heads, d).transpose(0, 2, 1, 3).astype(np.float64)
+    s = (sp(qkv[..., :C]) / np.sqrt(d)) @ sp(qkv[..., C:2 * C]).transpose(0, 1, 3, 2)
+    pr = np.exp(s - s.max(-1, keepdims=True))
+    pr /= pr.sum(-1, keepdims=True)
+    ref = (pr @ sp(qkv[..., 2 * C:])).transpose(0, 2, 1, 3).reshape(B, N, C).astype(np.float32)
+    assert np.abs(fused - ref).max() < 0.15          # bf16 rounding of q, k, v, p under a fairly sharp softmax
+    assert np.abs(fused - ref).mean() < 5e-3
 
 
 def test_attention_bf16_spiky_and_shifted(ops):
