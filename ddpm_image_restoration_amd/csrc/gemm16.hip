@@ -52,17 +52,20 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
   const int m0 = bx * BM, n0 = blockIdx.y * (NT * 32);
   const int nck = (p.Cin + BK - 1) / BK;
-  const int nit_all = p.taps * nck;
+  const int nit_main = p.taps * nck;
+  const int nit_all = nit_main + (p.Cinb + BK - 1) / BK;
   const int nsplit = gridDim.z, sk = blockIdx.z;
   const int it0 = (int)((long long)nit_all * sk / nsplit), it1 = (int)((long long)nit_all * (sk + 1) / nsplit);
   const int nit = (p.dbg & 16) ? 0 : it1 - it0;
   const __bf16* A16 = reinterpret_cast<const __bf16*>(p.A16);
   const __bf16* W16 = reinterpret_cast<const __bf16*>(p.Wt16);
+  const __bf16* A16b = reinterpret_cast<const __bf16*>(p.A16b);
+  const __bf16* W16b = reinterpret_cast<const __bf16*>(p.Wt16b);
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zero16);
   const unsigned lds0 = (unsigned)(size_t)smem;
 
   // per-thread DMA slots: slot s = j*256 + tid covers LDS row s / CPR, chunk position s % CPR
-  int a_y[AL], a_x[AL];
+  int a_y[AL], a_x[AL], a_m[AL];
   bool a_ok[AL];
   size_t a_off[AL];
   int a_chunk[AL];
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
     const int b = mm / HW, rem = mm - b * HW;
     a_y[j] = rem / p.W; a_x[j] = rem - a_y[j] * p.W;
     a_ok[j] = ok;
-    a_off[j] = (size_t)mm * p.lda16;
+    a_off[j] = (size_t)mm * p.lda16; a_m[j] = mm;
     a_chunk[j] = pos ^ ((row >> RSH) & (CPR - 1));     // which 8-channel chunk of the row this slot holds
   }
   int b_n[BL], b_chunk[BL];
@@ -88,6 +91,25 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
 
   auto issue = [&](int itl) {
     const int it = it0 + itl;
+    const unsigned sbase2 = lds0 + (itl % STAGES) * STAGE;
+    if (it >= nit_main) {   // second K segment: 1x1 operand pair (wave-uniform branch)
+      const int c0 = (it - nit_main) * BK;
+#pragma unroll
+      for (int j = 0; j < AL; ++j) {
+        const int c = c0 + 8 * a_chunk[j];
+        const bool ok = a_ok[j] && c < p.Cinb;
+        const void* g = ok ? (const void*)(A16b + (size_t)a_m[j] * p.lda16b + c) : (const void*)zero;
+        __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sbase2 + (j * 256 + wave * 64) * 16), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < BL; ++j) {
+        const int c = c0 + 8 * b_chunk[j];
+        const bool ok = b_n[j] < p.Cout && c < p.Cinb;
+        const void* g = ok ? (const void*)(W16b + (size_t)b_n[j] * p.Cinb + c) : (const void*)zero;
+        __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sbase2 + A_BYTES + (j * 256 + wave * 64) * 16), 16, 0, 0);
+      }
+      return;
+    }
     const int tap = it / nck;
     const int c0 = (it - tap * nck) * BK;
     int dy = 0, dx = 0;
@@ -368,7 +390,7 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
     attr = true;
   }
   const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
-  const int nit = p.taps * cdiv(p.Cin, BK);
+  const int nit = p.taps * cdiv(p.Cin, BK) + cdiv(p.Cinb, BK);
   int nsplit = 1;
   const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && !p.out16 && p.out && !p.pk_q && !p.sel_C &&
                       (!p.res || p.res != p.out || p.ldres == p.ldo);
@@ -389,7 +411,7 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
   const int64_t tiles = cdiv64(M, BM) * cdiv(p.Cout, NT * 32);
   const bool bk64 = (p.dbg & 32) ? true : (p.dbg & 64) ? false : tiles < 256;
   if (bk64) launch_nt<NT, 64, 3>(p, M, stream);
-  else if (p.taps * cdiv(p.Cin, 32) <= 2 && !(p.dbg & 128)) launch_nt<NT, 32, 2>(p, M, stream);
+  else if (p.taps * cdiv(p.Cin, 32) + cdiv(p.Cinb, 32) <= 2 && !(p.dbg & 128)) launch_nt<NT, 32, 2>(p, M, stream);
   else launch_nt<NT, 32, 3>(p, M, stream);
 }
 
@@ -405,6 +427,8 @@ void launch_gemm16(const IGemm& p, hipStream_t stream) {
   if (p.pk_q && !(p.Cout == 192 && p.taps == 1 && p.bias && p.pk_kv && p.pk_kmax && ((p.H * p.W) % 32) == 0 &&
                   p.pk_nt * 32 == p.H * p.W && p.epi_act == ACT_NONE && !p.mul && !p.res && !p.tb))
     throw std::runtime_error("gemm16: fused qkv packing needs Cout = 192 (4 heads x 16), whole 32-token tiles, plain epilogue");
+  if (p.Cinb && !(p.A16b && p.Wt16b && (p.Cinb % 8) == 0 && (p.lda16b % 8) == 0))
+    throw std::runtime_error("gemm16: second K segment needs bf16 operands with channel counts that are multiples of 8");
   if (p.sel_C && !(p.Cout == 2 * p.sel_C && (p.sel_C % 64) == 0))
     throw std::runtime_error("gemm16: gate selection needs Cout = 2 * sel_C with sel_C a multiple of 64");
   const int64_t M = (int64_t)p.B * p.H * p.W;

@@ -40,6 +40,9 @@ struct IGemm {
   // [sel_C, 2 sel_C) the high-frequency gate; a row only stores the half that matches its pixel class, at column n mod sel_C
   // (mul / res / out / out16 are indexed with that column; rowscale applies to the high half only)
   int sel_C = 0;
+  // second K segment (gemm16.hip): a 1x1 operand pair appended after the taps of the first, e.g. the block's 1x1
+  // shortcut conv folded into conv_out (out = W_out * S + W_sc * x + (b_out + b_sc)): saves one write + read of `out`
+  const void* A16b = nullptr; int lda16b = 0; const void* Wt16b = nullptr; int Cinb = 0;
   void* pk_q = nullptr; void* pk_kv = nullptr; float* pk_kmax = nullptr; int pk_nt = 0; float pk_qscale = 0.f;
   int dbg = 0;   // timing experiments only: 1 skip A loads, 2 skip B loads, 4 skip MFMA, 8 skip stores, 16 skip LDS writes
 };

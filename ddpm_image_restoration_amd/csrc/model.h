@@ -51,6 +51,7 @@ struct BlockW {
   // WebP / JPEG frequency block
   float* dct = nullptr;
   ConvW low0, low2, high0, high2;
+  float* co_bias = nullptr;   // conv_out.bias + shortcut.bias (shortcut folded into conv_out as a second K segment)
   ConvW fg1, fg2;   // DMA-GEMM path: both gates stacked (C -> [low hid | high hid]) and block-diagonal ([hid] -> [low | high])
   // AVIF frequency block
   AvifTransformW at;
@@ -140,7 +141,7 @@ class Context {
   void forward(const float* x, const float* t, const float* cl, float* out, hipStream_t s);
   void run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
   void run_block16(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
-  void conv16(const ConvW& cw, IGemm p, hipStream_t s);
+  void conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override = nullptr);
   bool use_gemm16() const { return cfg.dtype == DDPMIR_BF16 && cfg.arch != DDPMIR_ARCH_AVIF; }
   void freq_dct(const BlockW& bw, int H, int W, hipStream_t s);
   void freq_avif(const BlockW& bw, int H, int W, hipStream_t s);

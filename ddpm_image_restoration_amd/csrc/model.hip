@@ -241,6 +241,16 @@ void Context::layout_weights(Arena& a, bool up) {
     }
     put_conv(a, up, b.conv_out, fg + ".conv_out", d.cout, d.cout, 3);
     if (b.has_shortcut) put_conv(a, up, b.shortcut, n + ".shortcut", d.cout, d.cin, 1);
+    if (b.has_shortcut && use_gemm16()) {
+      b.co_bias = a.take<float>(d.cout);
+      if (up) {
+        const auto& b1 = host_.at(fg + ".conv_out.bias").data;
+        const auto& b2 = host_.at(n + ".shortcut.bias").data;
+        std::vector<float> sum(d.cout);
+        for (int i = 0; i < d.cout; ++i) sum[i] = b1[i] + b2[i];
+        DDPMIR_HIP_CHECK(hipMemcpy(b.co_bias, sum.data(), sum.size() * 4, hipMemcpyHostToDevice));
+      }
+    }
   }
   if (avif) {
     put(a, up, head_at_.tw, "avif_layer.transform_weights", 64 * 64);
@@ -510,8 +520,8 @@ void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
   launch_mul4_add(p.hB, C, p.xt, C, p.avg, C, p.col, C, p.edge, C, p.S, C, M, C, s);
 }
 
-void Context::conv16(const ConvW& cw, IGemm p, hipStream_t s) {
-  p.Wt = nullptr; p.Wt16 = cw.w16; p.bias = cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
+void Context::conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override) {
+  p.Wt = nullptr; p.Wt16 = cw.w16; p.bias = bias_override ? bias_override : cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
   p.zero16 = plan_.zero16;
   if (gemm16_supported(p)) launch_gemm16(p, s);
   else throw std::logic_error("conv16: operand layout not supported by the DMA GEMM");
@@ -587,15 +597,23 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
     d.out16 = p.S16; d.ldo16 = C;
     conv16(bw.high2, d, s);
   }
-  // shortcut + conv_out
-  const float* res = in; int ldres = ldin;
-  if (bw.has_shortcut) {
-    IGemm sc = g; sc.A16 = p.x16; sc.lda16 = cin8; sc.out = dest; sc.ldo = lddest;
-    conv16(bw.shortcut, sc, s);
-    res = dest; ldres = lddest;
+  // conv_out + residual; a 1x1 shortcut conv rides along as a second K segment of the same GEMM (identity shortcuts
+  // are the plain fp32 residual)
+  IGemm co = g; co.A16 = p.S16; co.lda16 = C; co.out = dest; co.ldo = lddest;
+  static const bool split_sc = getenv("DDPMIR_SPLIT_SHORTCUT") != nullptr;   // A/B: separate shortcut GEMM
+  if (bw.has_shortcut && !split_sc) {
+    co.A16b = p.x16; co.lda16b = cin8; co.Wt16b = bw.shortcut.w16; co.Cinb = bw.shortcut.cin16;
+    conv16(bw.conv_out, co, s, bw.co_bias);
+  } else {
+    if (bw.has_shortcut) {
+      IGemm sc = g; sc.A16 = p.x16; sc.lda16 = cin8; sc.out = dest; sc.ldo = lddest;
+      conv16(bw.shortcut, sc, s);
+      co.res = dest; co.ldres = lddest;
+    } else {
+      co.res = in; co.ldres = ldin;
+    }
+    conv16(bw.conv_out, co, s);
   }
-  IGemm co = g; co.A16 = p.S16; co.lda16 = C; co.res = res; co.ldres = ldres; co.out = dest; co.ldo = lddest;
-  conv16(bw.conv_out, co, s);
 }
 
 void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest,

@@ -192,6 +192,40 @@ int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int b
   });
 }
 
+int ddpmir_op_conv_dual_bf16(const float* x1, int B, int H, int W, int C1, const float* w1_oihw, int ksize, const float* x2,
+                             int C2, const float* w2_oi, const float* bias, int Cout, float* out) {
+  return guarded([&] {
+    if (Cout % 4) throw std::runtime_error("conv_dual: Cout must be a multiple of 4");
+    Dev d;
+    const int taps = ksize * ksize, c18 = round_up(C1, 8), c28 = round_up(C2, 8);
+    const size_t M = (size_t)B * H * W;
+    auto bf = [](float f) {
+      unsigned int u;
+      memcpy(&u, &f, 4);
+      return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    };
+    std::vector<unsigned short> wa((size_t)taps * Cout * c18, 0), wb((size_t)Cout * c28, 0), xa(M * c18, 0), xb(M * c28, 0);
+    for (int o = 0; o < Cout; ++o) {
+      for (int c = 0; c < C1; ++c)
+        for (int t = 0; t < taps; ++t) wa[((size_t)t * Cout + o) * c18 + c] = bf(w1_oihw[((size_t)o * C1 + c) * taps + t]);
+      for (int c = 0; c < C2; ++c) wb[(size_t)o * c28 + c] = bf(w2_oi[(size_t)o * C2 + c]);
+    }
+    for (size_t m = 0; m < M; ++m) {
+      for (int c = 0; c < C1; ++c) xa[m * c18 + c] = bf(x1[m * C1 + c]);
+      for (int c = 0; c < C2; ++c) xb[m * c28 + c] = bf(x2[m * C2 + c]);
+    }
+    IGemm p;
+    p.B = B; p.H = H; p.W = W; p.Cin = c18; p.Cout = Cout; p.taps = taps; p.bias = d.up(bias, Cout);
+    p.A16 = d.up(xa.data(), xa.size()); p.lda16 = c18; p.Wt16 = d.up(wa.data(), wa.size());
+    p.A16b = d.up(xb.data(), xb.size()); p.lda16b = c28; p.Wt16b = d.up(wb.data(), wb.size()); p.Cinb = c28;
+    p.zero16 = d.alloc<unsigned char>(256);
+    float* o = d.alloc<float>(M * Cout);
+    p.out = o; p.ldo = Cout;
+    launch_gemm16(p, nullptr);
+    d.down(out, o, M * Cout);
+  });
+}
+
 int ddpmir_op_qkv_attention_bf16(const float* x, int B, int N, int C, int heads, const float* w_in, const float* b_in,
                                  int fused, float* out) {
   return guarded([&] {

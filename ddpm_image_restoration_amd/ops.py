@@ -19,6 +19,7 @@ _sigs = {
     "ddpmir_op_gn_scale_shift": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "ddpmir_op_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ddpmir_op_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ddpmir_op_conv_dual_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P]),
     "ddpmir_op_qkv_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "ddpmir_op_attention_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ddpmir_op_block_transform": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float,
@@ -112,6 +113,18 @@ def attention(qkv, heads, bf16=False):
     out = np.empty((b, n, c3 // 3), np.float32)
     fn = lib.ddpmir_op_attention_bf16 if bf16 else lib.ddpmir_op_attention
     _chk(lib, fn(_p(qkv), b, n, c3 // 3, heads, _p(out)), "op_attention")
+    return out
+
+
+def conv_dual_bf16(x1, w1, x2, w2, bias):
+    """conv(x1, w1 [Cout,C1,k,k]) + conv1x1(x2, w2 [Cout,C2]) + bias in one launch; NHWC in/out."""
+    lib = _lib_ops()
+    x1, w1, x2, w2, bias = _f(x1), _f(w1), _f(x2), _f(w2), _f(bias)
+    b, h, wd, c1 = x1.shape
+    cout, _, k, _ = w1.shape
+    out = np.empty((b, h, wd, cout), np.float32)
+    _chk(lib, lib.ddpmir_op_conv_dual_bf16(_p(x1), b, h, wd, c1, _p(w1), k, _p(x2), x2.shape[-1], _p(w2), _p(bias), cout,
+                                           _p(out)), "op_conv_dual")
     return out
 
 

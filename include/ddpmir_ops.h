@@ -41,6 +41,10 @@ int ddpmir_op_gn_scale_shift(const float* x, int B, int HW, int C, int G, const 
 int ddpmir_op_attention(const float* qkv, int B, int N, int C, int heads, float* out);
 /* same through the bf16 matrix-core kernel (fp32 in/out, bf16 operands, fp32 accumulation) */
 int ddpmir_op_attention_bf16(const float* qkv, int B, int N, int C, int heads, float* out);
+/* out = conv_kxk(x1, w1) + conv_1x1(x2, w2) + bias in ONE DMA-GEMM launch (second K segment): conv_out with the block's
+ * 1x1 shortcut folded in (webp_inference.py:326-327).  x1 [B,H,W,C1], x2 [B,H,W,C2], out [B,H,W,Cout]. */
+int ddpmir_op_conv_dual_bf16(const float* x1, int B, int H, int W, int C1, const float* w1_oihw, int ksize, const float* x2,
+                             int C2, const float* w2_oi, const float* bias, int Cout, float* out);
 /* qkv projection (nn.MultiheadAttention in_proj, webp_inference.py:295) + attention core through the bf16 path:
  * x [B,N,C] -> out [B,N,C] (before out_proj).  fused = 1: the projection's epilogue writes the attention operand
  * images directly (head_dim 16, 4 heads, N % 32 == 0); fused = 0: fp32 qkv tensor + separate packing kernel. */

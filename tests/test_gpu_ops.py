@@ -85,6 +85,22 @@ def test_conv_bf16_dma_gate_select(ops, H, W, bs, low):
     close(nchw(got), ref.astype(np.float32), 2e-5)
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(2, 16, 16, 64, 128, 64), (1, 8, 8, 512, 1024, 512), (2, 32, 32, 64, 3, 64),
+                                              (1, 4, 4, 1024, 512, 1024), (3, 5, 9, 40, 24, 36)])
+def test_conv_bf16_dma_second_k_segment(ops, B, H, W, C1, C2, Cout):
+    """3x3 conv_out with the block's 1x1 shortcut conv folded in as a second K segment (incl. split-K shapes)."""
+    def bf(z):
+        u = np.ascontiguousarray(z, dtype=np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    x1, x2 = rnd(B, C1, H, W, seed=30), rnd(B, C2, H, W, seed=31)
+    w1 = rnd(Cout, C1, 3, 3, seed=32, scale=1.0 / np.sqrt(9 * C1))
+    w2 = rnd(Cout, C2, seed=33, scale=1.0 / np.sqrt(C2))
+    b = rnd(Cout, seed=34)
+    got = ops.conv_dual_bf16(nhwc(x1), w1, nhwc(x2), w2, b)
+    ref = O.conv2d(bf(x1), bf(w1), b, 1) + O.conv2d(bf(x2), bf(w2)[:, :, None, None], np.zeros(Cout, np.float32), 0)
+    close(nchw(got), ref, 4e-5)
+
+
 def test_conv_bf16_fused_prologue_epilogue(ops):
     B, H, W, C, Co = 2, 16, 16, 64, 128
     x = rnd(B, C, H, W, seed=4, scale=2.0) + 0.5
