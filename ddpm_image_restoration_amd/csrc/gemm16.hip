@@ -48,9 +48,16 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = p.B * p.H * p.W, HW = p.H * p.W;
   // XCD-aware placement: consecutive M tiles (which share 3x3 halo rows) run on the same XCD / L2
-  int bx = blockIdx.x;
-  if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
-  const int m0 = bx * BM, n0 = blockIdx.y * (NT * 32);
+  // Weight-bound shapes (few M tiles, BK = 64 variant): blockIdx.x is the N tile instead, so the M tiles that stream the
+  // SAME weight slice get workgroup ids a multiple of gridDim.x apart = the same XCD, and the slice is fetched into one
+  // L2 instead of eight (the activations are small enough to sit in every L2).
+  int bx, by;
+  if (BK == 64) { bx = blockIdx.y; by = blockIdx.x; }
+  else {
+    bx = blockIdx.x; by = blockIdx.y;
+    if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+  }
+  const int m0 = bx * BM, n0 = by * (NT * 32);
   const int nck = (p.Cin + BK - 1) / BK;
   const int nit_main = p.taps * nck;
   const int nit_all = nit_main + (p.Cinb + BK - 1) / BK;
@@ -61,7 +68,8 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   const __bf16* W16 = reinterpret_cast<const __bf16*>(p.Wt16);
   const __bf16* A16b = reinterpret_cast<const __bf16*>(p.A16b);
   const __bf16* W16b = reinterpret_cast<const __bf16*>(p.Wt16b);
-  const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zero16);
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zero16) +
+                              (((blockIdx.x + 3 * blockIdx.y + 5 * blockIdx.z) & 15) * 256 + tid) * 16;   // 16 x 4 KiB windows
   const unsigned lds0 = (unsigned)(size_t)smem;
 
   // per-thread DMA slots: slot s = j*256 + tid covers LDS row s / CPR, chunk position s % CPR
@@ -392,8 +400,9 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
   const int nit = p.taps * cdiv(p.Cin, BK) + cdiv(p.Cinb, BK);
   int nsplit = 1;
-  const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && !p.out16 && p.out && !p.pk_q && !p.sel_C &&
-                      (!p.res || p.res != p.out || p.ldres == p.ldo);
+  // (a bf16 copy of the result does not prevent split-K: it is converted from the fp32 sums afterwards)
+  const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && p.out && !p.pk_q && !p.sel_C &&
+                      (!p.out16 || (p.Cout % 8) == 0) && (!p.res || p.res != p.out || p.ldres == p.ldo);
   if (linear && gx * gy < 256 && nit >= 8 * (64 / BK)) {
     nsplit = std::min(std::min(16, nit / (4 * (64 / BK))), cdiv(512, gx * gy));
     if (nsplit < 1) nsplit = 1;
@@ -401,7 +410,14 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   if (nsplit > 1 && !(p.res && p.res == p.out))
     hipLaunchKernelGGL(zero_rows16_k, dim3((unsigned)std::min<int64_t>(cdiv64(M * (p.Cout / 4), 256), 2048)), dim3(256), 0,
                        stream, p.out, p.ldo, M, p.Cout / 4);
-  hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES>), dim3(gx, gy, nsplit), dim3(256), LDS, stream, p);
+  if (nsplit > 1 && p.out16) {
+    IGemm q = p;
+    q.out16 = nullptr;
+    hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES>), BK == 64 ? dim3(gy, gx, nsplit) : dim3(gx, gy, nsplit), dim3(256), LDS, stream, q);
+    launch_gn_apply16(p.out, p.ldo, p.B, p.H * p.W, p.Cout, nullptr, nullptr, ACT_NONE, p.out16, p.ldo16, nullptr, 0, stream);
+    return;
+  }
+  hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES>), BK == 64 ? dim3(gy, gx, nsplit) : dim3(gx, gy, nsplit), dim3(256), LDS, stream, p);
 }
 
 template <int NT>

@@ -9,6 +9,10 @@ namespace ddpmir {
 // ------------------------------------------------------------------------------------------------ igemm
 // out[m][n] = epilogue( sum_{tap,c} prologue(A[pix(m)+tap][c]) * Wt[tap][n][c] )
 // Covers nn.Conv2d 3x3 pad 1 (taps=9), 1x1 conv / nn.Linear (taps=1).  Reference: a3/a4/a6/a8 of SURVEY 8(a).
+// The zero page the DMA GEMM reads halo / tail chunks from.  64 KiB, not 16 B: every lane of every workgroup reads its
+// own 16-byte slot, so border-heavy shapes (8x8 maps: 30 % of the A loads) do not all hammer one L2 channel.
+constexpr int GEMM16_ZERO_BYTES = 65536;
+
 struct IGemm {
   // input
   const float* A = nullptr; int lda = 0;      // [B*H*W][lda], channels 0..Cin-1 used (Cin % 4 == 0)
@@ -32,7 +36,7 @@ struct IGemm {
   float* out = nullptr; int ldo = 0; int store = STORE_NHWC;
   // DMA-streamed bf16 path (gemm16.hip): A already holds what the GEMM consumes, as bf16 [B*H*W][lda16]
   const void* A16 = nullptr; int lda16 = 0;
-  const void* zero16 = nullptr;               // >= 16 bytes of zeros in device memory (halo / tail source)
+  const void* zero16 = nullptr;               // GEMM16_ZERO_BYTES of zeros in device memory (halo / tail source)
   void* out16 = nullptr; int ldo16 = 0;       // optional bf16 copy of the epilogue result (out may then be null)
   // qkv projection fused with the attention operand packing (head_dim 16, 4 heads, C = 64: gemm16.hip epilogue writes
   // the Q / K / V^T images of attention_bf16.hip directly instead of an fp32 [M][192] tensor); see AttnPack16

@@ -333,7 +333,7 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
     p.a16 = a.take<unsigned short>(ma); p.x16 = a.take<unsigned short>(ma);
     p.hB16 = a.take<unsigned short>(mc); p.att16 = a.take<unsigned short>(mc); p.xdl16 = a.take<unsigned short>(mc);
     p.xdh16 = a.take<unsigned short>(mc); p.hid16 = a.take<unsigned short>(mc); p.S16 = a.take<unsigned short>(mc);
-    p.zero16 = a.take<unsigned char>(256);
+    p.zero16 = a.take<unsigned char>(GEMM16_ZERO_BYTES);
   }
   int max_splits = gn_splits(H * W, 64);
   p.gn_partial = a.take<double>((size_t)B * 8 * max_splits * 2 + 64);
