@@ -12,6 +12,14 @@ tot = sum(v[1] for v in agg.values())
 print(f"total kernel time {tot/1e3:.2f} ms over {n_fwd} forwards = {tot/1e3/n_fwd:.2f} ms/forward")
 for k, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
     print(f"{k[:60]:60s} calls/fwd={c/n_fwd:6.1f} ms/fwd={us/1e3/n_fwd:8.3f}")
+# the roofline kernel: level-0 attention launches only (the largest grid of flash_bf16<16,...>); bench.py's
+# roofline.avg_launch_ms is the HIP-event average of exactly these dispatches
+fl = [r for r in rows if "flash_bf16<16" in r["Kernel_Name"]]
+if fl:
+    gmax = max(int(r["Grid_Size_X"]) for r in fl)
+    l0 = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in fl if int(r["Grid_Size_X"]) == gmax]
+    print(f"level-0 attention (flash_bf16<16>, grid {gmax // 256} workgroups): {len(l0)} launches, "
+          f"avg {sum(l0) / len(l0):.3f} ms, min {min(l0):.3f}, max {max(l0):.3f}")
 if len(sys.argv) > 3:
     ig = [r for r in rows if sys.argv[3] in r["Kernel_Name"]]
     n = len(ig) // n_fwd
