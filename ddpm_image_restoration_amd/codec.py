@@ -3,18 +3,24 @@
 Same calls as the reference's webp_compress / jpeg_compress / avif_compress (webp_inference.py:506-528,
 svd.ipynb c0:45-69, avif_inference.py:64-98): Pillow encode -> decode per image, same quality clamps, JPEG
 subsampling 4:4:4 above q30 else 4:2:0, AVIF silently falling back to JPEG on an encoder error.  Images move as
-uint8 NCHW; a thread pool spreads the per-image work over the host cores (Pillow releases the GIL inside the
-codec libraries).
+uint8 NCHW; a thread pool spreads the per-image work over the host cores (Pillow releases the GIL inside libjpeg /
+libwebp: 16 WebP images take 83 ms sequentially and 12 ms from 16 threads on the MI355X host).  Pillow's AVIF encoder
+does not scale across threads (591 ms -> 454 ms), so AVIF batches go to a pool of worker PROCESSES over shared memory
+(`_codec_worker.py`; DDPMIR_AVIF_WORKERS=0 disables it, =N sets the worker count).
 """
 from __future__ import annotations
 
+import atexit
 import io
 import os
+import subprocess
+import sys
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
 _pool = None
+_procs = None
 
 
 def _get_pool() -> ThreadPoolExecutor:
@@ -46,6 +52,81 @@ def _one(img_chw: np.ndarray, quality: int, kind: str) -> np.ndarray:
     return np.asarray(Image.open(buf).convert("RGB"), dtype=np.uint8).transpose(2, 0, 1)
 
 
+class _ProcPool:
+    """Worker processes + two shared-memory blocks (batch in / batch out); see _codec_worker.py."""
+
+    def __init__(self, workers: int, nbytes: int):
+        from multiprocessing import shared_memory
+        self.nbytes = nbytes
+        self.shm_in = shared_memory.SharedMemory(create=True, size=nbytes)
+        self.shm_out = shared_memory.SharedMemory(create=True, size=nbytes)
+        env = dict(os.environ)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        cmd = [sys.executable, "-m", "ddpm_image_restoration_amd._codec_worker", self.shm_in.name, self.shm_out.name]
+        self.procs = [subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1, env=env)
+                      for _ in range(workers)]
+
+    def run(self, u8: np.ndarray, quality: int, kind: str, out: np.ndarray) -> None:
+        b, _, h, w = u8.shape
+        np.ndarray(u8.shape, dtype=np.uint8, buffer=self.shm_in.buf)[...] = u8
+        n = len(self.procs)
+        for i in range(b):   # image i -> worker i mod n; every worker serves its requests in order
+            self.procs[i % n].stdin.write(f"{i} {h} {w} {int(quality)} {kind}\n")
+        for p in self.procs[:min(n, b)]:
+            p.stdin.flush()
+        for i in range(b):
+            reply = self.procs[i % n].stdout.readline().strip()
+            if reply != "ok":
+                raise RuntimeError(f"codec worker failed on image {i}: {reply or 'worker exited'}")
+        out[...] = np.ndarray(u8.shape, dtype=np.uint8, buffer=self.shm_out.buf)
+
+    def close(self) -> None:
+        for p in self.procs:
+            try:
+                p.stdin.write("quit\n"); p.stdin.flush(); p.stdin.close()
+            except Exception:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:
+                p.kill()
+        for shm in (self.shm_in, self.shm_out):
+            try:
+                shm.close(); shm.unlink()
+            except Exception:
+                pass
+
+
+def _avif_workers(batch: int) -> int:
+    env = os.environ.get("DDPMIR_AVIF_WORKERS")
+    if env is not None:
+        return max(0, int(env))
+    return max(1, min(batch, 16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)))
+
+
+def _get_procs(nbytes: int, batch: int):
+    global _procs
+    workers = _avif_workers(batch)
+    if workers == 0:
+        return None
+    if _procs is not None and (_procs.nbytes < nbytes or len(_procs.procs) < workers):
+        _procs.close()
+        _procs = None
+    if _procs is None:
+        _procs = _ProcPool(workers, nbytes)
+        atexit.register(_shutdown_procs)
+    return _procs
+
+
+def _shutdown_procs() -> None:
+    global _procs
+    if _procs is not None:
+        _procs.close()
+        _procs = None
+
+
 def roundtrip_u8(u8_nchw: np.ndarray, quality: int, kind: str, out: np.ndarray | None = None) -> np.ndarray:
     """decode(encode(img, quality)) for every image of a uint8 [B,3,H,W] batch."""
     b = u8_nchw.shape[0]
@@ -54,6 +135,11 @@ def roundtrip_u8(u8_nchw: np.ndarray, quality: int, kind: str, out: np.ndarray |
     if b == 1:
         out[0] = _one(u8_nchw[0], quality, kind)
         return out
+    if kind == "avif":
+        pool = _get_procs(u8_nchw.nbytes, b)
+        if pool is not None:
+            pool.run(np.ascontiguousarray(u8_nchw), quality, kind, out)
+            return out
     for i, res in enumerate(_get_pool().map(lambda im: _one(im, quality, kind), list(u8_nchw))):
         out[i] = res
     return out

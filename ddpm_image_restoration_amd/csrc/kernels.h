@@ -91,6 +91,10 @@ void launch_bilinear(const float* in, int ldi, float* out, int ldo, int B, int H
                      int C, float scale_h, float scale_w, int accumulate, float out_scale, hipStream_t s);
 void launch_adaptive_avgpool(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int S,
                              hipStream_t s);
+// all four AdaptiveAvgPool2d scales {1,2,4,8} from one pass: bin sums [B][64][C], then folded per scale
+bool pool8_supported(int H, int W, int C);
+void launch_pool8_sums(const float* in, int ldi, float* sums, int B, int H, int W, int C, hipStream_t s);
+void launch_pool_from8(const float* sums, float* out, int ldo, int B, int H, int W, int C, int S, hipStream_t s);
 
 // blockwise Y = T X T^T (block bs in {4,8}); mats: one [bs][bs] matrix (per_channel=0) or [C][bs][bs].
 // out = mix_in * x + mix_t * Y   (mix_in=0,mix_t=1: plain transform; head: 1, 0.1)

@@ -115,7 +115,7 @@ class Context {
     float *bb0 = nullptr, *bb1 = nullptr, *bb2 = nullptr;
     float* u[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // outputs of up blocks, index = level
     float *hA = nullptr, *hB = nullptr, *qkv = nullptr, *att = nullptr, *xd = nullptr, *hid = nullptr, *S = nullptr;
-    float *xt = nullptr, *avg = nullptr, *col = nullptr, *edge = nullptr, *pool = nullptr, *pg1 = nullptr, *pg2 = nullptr;
+    float *xt = nullptr, *avg = nullptr, *col = nullptr, *edge = nullptr, *pool = nullptr, *pool8 = nullptr, *pg1 = nullptr, *pg2 = nullptr;
     unsigned char* attn_ws = nullptr;
     // bf16 operand tensors of the DMA-streamed GEMM path (dtype = bf16, DCT families)
     unsigned short *a16 = nullptr, *x16 = nullptr, *hB16 = nullptr, *att16 = nullptr, *xdl16 = nullptr, *xdh16 = nullptr,
@@ -142,7 +142,7 @@ class Context {
   void run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
   void run_block16(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
   void conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override = nullptr);
-  bool use_gemm16() const { return cfg.dtype == DDPMIR_BF16 && cfg.arch != DDPMIR_ARCH_AVIF; }
+  bool use_gemm16() const { return cfg.dtype == DDPMIR_BF16; }
   void freq_dct(const BlockW& bw, int H, int W, hipStream_t s);
   void freq_avif(const BlockW& bw, int H, int W, hipStream_t s);
   void avif_transform(const AvifTransformW& at, const float* x, int ldx, int C, int H, int W, float* T, float* tmp,

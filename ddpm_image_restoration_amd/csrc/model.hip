@@ -318,6 +318,7 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
   if (avif) {
     p.xt = a.take<float>(mc); p.avg = a.take<float>(mc); p.col = a.take<float>(mc); p.edge = a.take<float>(mc);
     p.pool = a.take<float>((size_t)B * 64 * 1024); p.pg1 = a.take<float>((size_t)B * 64 * 256);
+    p.pool8 = a.take<float>((size_t)B * 64 * 1024);
     p.pg2 = a.take<float>((size_t)B * 64 * 1024);
   }
   if (cfg.dtype == DDPMIR_BF16) {
@@ -480,8 +481,18 @@ void Context::avif_transform(const AvifTransformW& at, const float* x, int ldx, 
                              float* tmp, float* out, int ldo, const float* rowscale, const float* res, int ldres,
                              hipStream_t s) {
   const int B = fb_;
-  launch_block_transform(x, ldx, T, C, B, H, W, C, 8, at.tw, 1, 0.f, 1.f, s);
   IGemm g; g.B = B; g.H = H; g.W = W;
+  if (use_gemm16()) {   // bf16 copy of the transformed tensor feeds the two 1x1 "quantization" GEMMs by LDS-DMA
+    Plan& p = plan_;
+    launch_block_transform(x, ldx, T, C, B, H, W, C, 8, at.tw, 1, 0.f, 1.f, s, p.xdl16, nullptr, 0);
+    IGemm a = g; a.A16 = p.xdl16; a.lda16 = C; a.epi_act = ACT_RELU; a.out16 = p.hid16; a.ldo16 = C;
+    conv16(at.q0, a, s);
+    IGemm b = g; b.A16 = p.hid16; b.lda16 = C; b.epi_act = ACT_SIGMOID; b.mul = T; b.ldmul = C; b.rowscale = rowscale;
+    b.res = res; b.ldres = ldres; b.out = out; b.ldo = ldo;
+    conv16(at.q2, b, s);
+    return;
+  }
+  launch_block_transform(x, ldx, T, C, B, H, W, C, 8, at.tw, 1, 0.f, 1.f, s);
   IGemm a = g; a.A = T; a.lda = C; a.epi_act = ACT_RELU; a.out = tmp; a.ldo = C;
   conv(at.q0, a, s);
   IGemm b = g; b.A = tmp; b.lda = C; b.epi_act = ACT_SIGMOID; b.mul = T; b.ldmul = C; b.rowscale = rowscale;
@@ -496,9 +507,12 @@ void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
   const int64_t M = (int64_t)B * H * W;
   avif_transform(bw.at, p.hB, C, C, H, W, p.xd, p.hid, p.xt, C, nullptr, nullptr, 0, s);
   const int scales[4] = {1, 2, 4, 8};
+  const bool one_pass = pool8_supported(H, W, C);   // all four scales from one read of x
+  if (one_pass) launch_pool8_sums(p.hB, C, p.pool8, B, H, W, C, s);
   for (int i = 0; i < 4; ++i) {
     const int S = scales[i];
-    launch_adaptive_avgpool(p.hB, C, p.pool, C, B, H, W, C, S, s);
+    if (one_pass) launch_pool_from8(p.pool8, p.pool, C, B, H, W, C, S, s);
+    else launch_adaptive_avgpool(p.hB, C, p.pool, C, B, H, W, C, S, s);
     IGemm g; g.B = B; g.H = S; g.W = S;
     IGemm a = g; a.A = p.pool; a.lda = C; a.epi_act = ACT_RELU; a.out = p.pg1; a.ldo = C / 4;
     conv(bw.ms1[i], a, s);
@@ -509,6 +523,18 @@ void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
                     i == 3 ? 0.25f : 1.0f, s);
   }
   IGemm g; g.B = B; g.H = H; g.W = W;
+  if (use_gemm16()) {   // colour + edge gates on the bf16 copy of x (plan_.hB16, refreshed by out_proj)
+    IGemm c0 = g; c0.A16 = p.hB16; c0.lda16 = C; c0.epi_act = ACT_RELU; c0.out16 = p.hid16; c0.ldo16 = C;
+    conv16(bw.cc0, c0, s);
+    IGemm c2 = g; c2.A16 = p.hid16; c2.lda16 = C; c2.epi_act = ACT_SIGMOID; c2.rowscale = p.boost; c2.out = p.col; c2.ldo = C;
+    conv16(bw.cc2, c2, s);
+    IGemm e0 = g; e0.A16 = p.hB16; e0.lda16 = C; e0.epi_act = ACT_RELU; e0.out16 = p.hid16; e0.ldo16 = C / 2;
+    conv16(bw.ep0, e0, s);
+    IGemm e2 = g; e2.A16 = p.hid16; e2.lda16 = C / 2; e2.epi_act = ACT_SIGMOID; e2.rowscale = p.boost2; e2.out = p.edge; e2.ldo = C;
+    conv16(bw.ep2, e2, s);
+    launch_mul4_add(p.hB, C, p.xt, C, p.avg, C, p.col, C, p.edge, C, p.S, C, M, C, s);
+    return;
+  }
   IGemm c0 = g; c0.A = p.hB; c0.lda = C; c0.epi_act = ACT_RELU; c0.out = p.hid; c0.ldo = C;
   conv(bw.cc0, c0, s);
   IGemm c2 = g; c2.A = p.hid; c2.lda = C; c2.epi_act = ACT_SIGMOID; c2.rowscale = p.boost; c2.out = p.col; c2.ldo = C;
@@ -573,11 +599,17 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
     }
     prof_end(s);
     IGemm o = g; o.A16 = p.att16; o.lda16 = C; o.res = p.hB; o.ldres = C; o.out = p.hB; o.ldo = C;
+    if (cfg.arch == DDPMIR_ARCH_AVIF) { o.out16 = p.hB16; o.ldo16 = C; }   // the colour / edge gates read x as bf16
     conv16(bw.out_proj, o, s);
+  } else if (cfg.arch == DDPMIR_ARCH_AVIF) {
+    launch_gn_apply16(p.hB, C, B, HW, C, nullptr, nullptr, ACT_NONE, p.hB16, C, nullptr, 0, s);
   }
   // frequency block: DCT -> masked bf16 operands -> gates -> S (bf16 only, it feeds conv_out alone)
   static const bool split_gates = getenv("DDPMIR_SPLIT_GATES") != nullptr;   // A/B: the four separate gate GEMMs
-  if (!split_gates) {
+  if (cfg.arch == DDPMIR_ARCH_AVIF) {
+    freq_avif(bw, H, W, s);                                            // -> plan_.S (fp32)
+    launch_gn_apply16(p.S, C, B, HW, C, nullptr, nullptr, ACT_NONE, p.S16, C, nullptr, 0, s);
+  } else if (!split_gates) {
     launch_block_transform(p.hB, C, p.xd, C, B, H, W, C, k.dct_block, bw.dct, 0, 0.f, 1.f, s, p.xdl16, nullptr, k.low_size);
     IGemm a = g; a.A16 = p.xdl16; a.lda16 = C; a.epi_act = ACT_LRELU; a.out16 = p.hid16; a.ldo16 = C;
     conv16(bw.fg1, a, s);

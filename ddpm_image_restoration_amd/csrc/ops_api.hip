@@ -380,7 +380,14 @@ int ddpmir_op_adaptive_avgpool(const float* x, int B, int H, int W, int C, int S
     Dev d;
     size_t no = (size_t)B * S * S * C;
     float* o = d.alloc<float>(no);
-    launch_adaptive_avgpool(d.up(x, (size_t)B * H * W * C), C, o, C, B, H, W, C, S, nullptr);
+    float* dx = d.up(x, (size_t)B * H * W * C);
+    if (pool8_supported(H, W, C) && (S == 1 || S == 2 || S == 4 || S == 8)) {   // the model's one-pass path
+      float* sums = d.alloc<float>((size_t)B * 64 * C);
+      launch_pool8_sums(dx, C, sums, B, H, W, C, nullptr);
+      launch_pool_from8(sums, o, C, B, H, W, C, S, nullptr);
+    } else {
+      launch_adaptive_avgpool(dx, C, o, C, B, H, W, C, S, nullptr);
+    }
     d.down(out, o, no);
   });
 }

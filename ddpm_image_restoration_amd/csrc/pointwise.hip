@@ -216,6 +216,51 @@ __global__ void adaptive_avgpool_k(const float* __restrict__ in, int ldi, float*
   }
 }
 
+// AdaptiveAvgPool2d(s) for s in {1,2,4,8} from ONE pass over the tensor (avif_inference.py:227-234 pools the same x at
+// four scales): when H and W are multiples of 8 the bins of all four scales nest, so one workgroup per (sample, 8x8 bin)
+// streams its pixels (lanes over channels, the rest of the block over pixels), reduces through LDS and writes the bin
+// SUM; the four pooled maps are then folded from the 64 sums.
+__global__ __launch_bounds__(256) void pool8_sums_k(const float* __restrict__ in, int ldi, float* __restrict__ sums, int H,
+                                                    int W, int C4) {
+  __shared__ float4 red[256];
+  const int bin = blockIdx.x, b = blockIdx.y, by = bin >> 3, bx = bin & 7;
+  const int bh = H / 8, bw = W / 8, tid = threadIdx.x;
+  const int lpp = C4 < 256 ? C4 : 256, slots = 256 / lpp, slot = tid / lpp, c4 = tid - slot * lpp;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (slot < slots)
+    for (int i = slot; i < bh * bw; i += slots) {
+      const int y = by * bh + i / bw, x = bx * bw + i % bw;
+      const float4 v = *reinterpret_cast<const float4*>(in + (((size_t)b * H + y) * W + x) * ldi + 4 * c4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  red[tid] = acc;
+  __syncthreads();
+  if (tid < lpp) {
+    float4 t = red[tid];
+    for (int sl = 1; sl < slots; ++sl) { const float4 v = red[sl * lpp + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    *reinterpret_cast<float4*>(sums + (((size_t)b * 64 + bin) * C4 + tid) * 4) = t;
+  }
+}
+
+__global__ void pool_from8_k(const float* __restrict__ sums, float* __restrict__ out, int ldo, int B, int C4, int S, float inv) {
+  const int64_t total = (int64_t)B * S * S * C4;
+  const int f = 8 / S;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = i % C4;
+    int64_t q = i / C4;
+    const int xo = q % S; q /= S;
+    const int yo = q % S; const int b = q / S;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int yy = 0; yy < f; ++yy)
+      for (int xx = 0; xx < f; ++xx) {
+        const float4 v = *reinterpret_cast<const float4*>(sums + (((size_t)b * 64 + (yo * f + yy) * 8 + xo * f + xx) * C4 + c4) * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    *reinterpret_cast<float4*>(out + (((size_t)b * S + yo) * S + xo) * ldo + 4 * c4) =
+        make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+
 // ------------------------------------------------------------------------------------------- block transform
 // One thread = one (block, channel): Y = T X T^T with zero padding beyond H/W and cropping on store.
 // The transform matrix sits in LDS (shared matrix) or is streamed per channel; X lives in registers with
@@ -452,6 +497,20 @@ void launch_adaptive_avgpool(const float* in, int ldi, float* out, int ldo, int 
                              hipStream_t s) {
   int64_t total = (int64_t)B * S * S * (C / 4);
   hipLaunchKernelGGL(adaptive_avgpool_k, dim3(grid_for(total)), dim3(256), 0, s, in, ldi, out, ldo, B, H, W, C / 4, S);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+bool pool8_supported(int H, int W, int C) { return (H % 8) == 0 && (W % 8) == 0 && H * W >= 256 && (C % 4) == 0 && C <= 1024; }
+
+void launch_pool8_sums(const float* in, int ldi, float* sums, int B, int H, int W, int C, hipStream_t s) {
+  hipLaunchKernelGGL(pool8_sums_k, dim3(64, B), dim3(256), 0, s, in, ldi, sums, H, W, C / 4);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_pool_from8(const float* sums, float* out, int ldo, int B, int H, int W, int C, int S, hipStream_t s) {
+  const int64_t total = (int64_t)B * S * S * (C / 4);
+  hipLaunchKernelGGL(pool_from8_k, dim3(grid_for(total)), dim3(256), 0, s, sums, out, ldo, B, C / 4, S,
+                     1.0f / (float)((H / S) * (W / S)));
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

@@ -301,6 +301,10 @@ def test_pool_and_resample(ops):
     close(nchw(ops.upsample2(nhwc(x))), O.upsample2(x), 1e-6)
     for s in (1, 2, 4, 8):
         close(nchw(ops.adaptive_avgpool(nhwc(x), s)), O.adaptive_avg_pool(x, s), 1e-6)
+    for shape in ((3, 64, 32, 48), (1, 1024, 16, 16), (2, 256, 64, 64)):   # nested bins: one pass feeds all four scales
+        xb = rnd(*shape, seed=27)
+        for s in (1, 2, 4, 8):
+            close(nchw(ops.adaptive_avgpool(nhwc(xb), s)), O.adaptive_avg_pool(xb, s), 2e-6)
     small = rnd(2, 64, 2, 2, seed=29)
     for s in (1, 2, 4, 8):
         a = O.adaptive_avg_pool(small, s)

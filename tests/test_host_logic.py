@@ -78,3 +78,17 @@ def test_harness_ssim_matches_independent_restatement():
     # a dim smaller than the window is left unsmoothed (pytorch_msssim behaviour)
     small = torch.from_numpy(a[:, :, :8, :8])
     assert ssim(small, small) == pytest.approx(1.0, abs=1e-12)
+
+
+def test_avif_worker_process_pool_matches_in_process_codec(monkeypatch):
+    """The AVIF degradation operator spread over worker processes (shared-memory batch) returns exactly what the
+    in-process Pillow calls of avif_inference.py:64-98 return; DDPMIR_AVIF_WORKERS=0 keeps everything in-process."""
+    u8 = np.clip(synth.synth_images(5, 32, seed=11) * 127.5 + 127.5, 0, 255).astype(np.uint8)
+    monkeypatch.setenv("DDPMIR_AVIF_WORKERS", "3")
+    pooled = codec.roundtrip_u8(u8, 10, "avif")
+    again = codec.roundtrip_u8(u8[:4], 40, "avif")          # pool reuse, smaller batch, other quality
+    monkeypatch.setenv("DDPMIR_AVIF_WORKERS", "0")
+    assert np.array_equal(pooled, codec.roundtrip_u8(u8, 10, "avif"))
+    assert np.array_equal(again, codec.roundtrip_u8(u8[:4], 40, "avif"))
+    assert np.array_equal(pooled[0], codec._one(u8[0], 10, "avif"))
+    codec._shutdown_procs()
