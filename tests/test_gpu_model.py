@@ -258,3 +258,61 @@ def test_checkpoint_converter_roundtrip(tmp_path, golden, synth_state):
     torch.save(bad, tmp_path / "bad.pth")
     with pytest.raises(RuntimeError, match="missing"):
         convert_checkpoint(WebPDiffusionModel(device=dev), str(tmp_path / "bad.pth"), str(tmp_path / "x.npy"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json's full size (256x256, attention over all 65 536 tokens): the numpy oracle needs ~13 s per image and step
+# here, so parity at this size is checked through properties that do not depend on the size.
+def test_full_size_forward_properties(models):
+    import torch
+    m32, m16 = models(spec.ARCH_JPEG), models(spec.ARCH_JPEG, dtype="bf16")
+    x = tt(synth.synth_images(2, 256, seed=21))
+    t = torch.tensor([0.31, 0.87], device="cuda")
+    y32 = m32(x, t, t)
+    assert torch.isfinite(y32).all() and float(y32.abs().max()) <= 1.0           # tanh head
+    # images of a batch do not interact: each one alone gives bit-identical results (fp32 mode is deterministic)
+    assert torch.equal(m32(x[:1], t[:1], t[:1]), y32[:1])
+    assert torch.equal(m32(x[1:], t[1:], t[1:]), y32[1:])
+    # production mode (bf16 operands, fused qkv packing, split-K) against parity mode at full size, SURVEY H2 tolerance
+    y16 = m16(x, t, t)
+    err = (y16 - y32).abs()
+    assert float(err.max()) < 2e-2 and float(err.mean()) < 2e-3, (float(err.max()), float(err.mean()))
+
+
+def test_full_size_attention_is_a_convex_combination():
+    """N = 65 536 keys, head_dim 16: softmax rows sum to one, so a value tensor that is constant per channel must come
+    back unchanged whatever q and k are -- exercises the deferred rescale and the ones-row denominator over 2048 tiles."""
+    from ddpm_image_restoration_amd import ops
+    rng = np.random.default_rng(3)
+    B, N, C = 1, 65536, 64
+    qkv = np.empty((B, N, 3 * C), np.float32)
+    qkv[..., :2 * C] = rng.standard_normal((B, N, 2 * C)).astype(np.float32) * 1.5
+    vconst = rng.uniform(-2, 2, C).astype(np.float32)
+    qkv[..., 2 * C:] = vconst
+    qkv[0, 40000, C:C + 16] = qkv[0, 123, :16] * 6        # one dominant key late in the sequence for query 123
+    u = vconst.view(np.uint32)
+    v_bf16 = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    for bf16 in (True, False):
+        out = ops.attention(qkv, 4, bf16=bf16)
+        assert np.isfinite(out).all()
+        # bf16 path: numerator and denominator use the same rounded p, so the result is the bf16-rounded constant;
+        # fp32 path: 65 536 sequential fp32 accumulations per row leave ~2e-4 relative (measured), well inside 1e-3
+        want = v_bf16 if bf16 else vconst
+        assert (np.abs(out - want) / np.abs(want)).max() < (1e-3 if bf16 else 6e-4)
+
+
+def test_full_size_sampler_shards_and_codecs(models):
+    """Three timesteps of the T=1000 schedule at 256x256: batch shards with the global image offset reproduce the
+    unsharded run bit for bit (fp32 mode), and the device JPEG codec equals the host Pillow codec inside the loop."""
+    from ddpm_image_restoration_amd.sampler import DDRMJPEGSampler
+    s = DDRMJPEGSampler(models(spec.ARCH_JPEG))
+    y = tt(O.compress(synth.synth_images(2, 256, seed=22), 10, "jpeg"))
+    kw = dict(steps=1000, start_step=995, num_steps=3, seed=5)
+    full = s.sample(y, 10, **kw)
+    a = s.sample(y[:1], 10, image_offset=0, **kw)
+    b = s.sample(y[1:], 10, image_offset=1, **kw)
+    import torch
+    assert torch.equal(full, torch.cat([a, b]))
+    host = s.sample(y, 10, device_codec=False, **kw)
+    assert torch.equal(full, host)
+    assert torch.isfinite(full).all() and float(full.abs().max()) < 4.0    # x_t still carries the injected noise here
