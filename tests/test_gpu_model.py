@@ -316,3 +316,20 @@ def test_full_size_sampler_shards_and_codecs(models):
     host = s.sample(y, 10, device_codec=False, **kw)
     assert torch.equal(full, host)
     assert torch.isfinite(full).all() and float(full.abs().max()) < 4.0    # x_t still carries the injected noise here
+
+
+def test_full_size_forward_matches_oracle_fixture(models):
+    """fp32 HIP forward at 256x256 (65 536-token attention at level 0) against the numpy oracle's output for the same
+    seeded weights and image (tests/golden/jpeg_fwd256_oracle.npz, made by make_fullsize_oracle.py): north_star's 1e-3."""
+    import os
+    import torch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_fwd256_oracle.npz"))
+    assert int(g["seed_w"]) == 0                       # the `models` fixture loads synth weights with seed 0
+    x = tt(synth.synth_images(1, 256, seed=int(g["seed_x"])))
+    y = models(spec.ARCH_JPEG)(x, tt(g["t"]), tt(g["cl"])).cpu().numpy()
+    err = np.abs(y - g["y"])
+    assert err.max() < TOL, (err.max(), err.mean())
+    y16 = models(spec.ARCH_JPEG, dtype="bf16")(x, tt(g["t"]), tt(g["cl"])).cpu().numpy()
+    e16 = np.abs(y16 - g["y"])
+    assert e16.max() < 2e-2 and e16.mean() < 2e-3, (e16.max(), e16.mean())
+    print(f"256x256 forward vs oracle: fp32 max {err.max():.2e} mean {err.mean():.2e}; bf16 max {e16.max():.2e} mean {e16.mean():.2e}")
