@@ -145,13 +145,14 @@ def main():
 
     if env.rank == 0:
         line = {
-            "metric": "restored images/sec (256x256, T=1000)", "value": value, "unit": "images/sec",
+            "metric": "restored images/sec (%dx%d, T=%d)" % (R, R, T_STEPS), "value": value, "unit": "images/sec",
             "n_gpus": env.world, "steps": steps_timed, "warmup": W, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: JPEG restoration U-Net, %dx%d, batch %d/GPU, T=%d, JPEG q%d; "
+            "config": {"workload": "%s: JPEG restoration U-Net, %dx%d, batch %d/GPU, T=%d, JPEG q%d; "
                                    "step = one reverse-diffusion timestep (U-Net forward + codec round trip + DDRM update)"
-                                   % (R, R, B, T_STEPS, q),
+                                   % ("BASELINE configs[1]" if (R, B, q, args.attn, args.dtype) == (256, 16, 10, "all", "bf16")
+                                      else "variant of BASELINE configs[1]", R, R, B, T_STEPS, q),
                        "global_batch": n_total, "image": R, "T": T_STEPS, "quality": q, "attn_levels": args.attn,
                        "codec": "device JPEG round trip (bit-exact to libjpeg-turbo)" if dev_codec else "host Pillow/libjpeg-turbo callback",
                        "arithmetic": "bf16 matrix-core operands, fp32 accumulation/softmax/GroupNorm statistics, fp32 activations in HBM" if args.dtype == "bf16" else "fp32 matrix cores",

@@ -539,6 +539,8 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
       case 7: run_flash<16, 2, 16, 0, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 8: run_flash<16, 2, 8, 0, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 9: run_flash<16, 1, 16, 0, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 10: run_flash<16, 2, 8, 3, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 11: run_flash<16, 2, 4, 3, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       default: break;
     }
   }
