@@ -28,11 +28,12 @@ namespace {
 
 constexpr int BM = 128;
 
-// BK = K elements per stage (64 or 32).  BK = 32 halves the stage so three workgroups fit one CU (48 KiB each):
-// one workgroup's barrier waits, LDS-read latency and epilogue overlap the MFMAs of the other two.
-// STAGES = 3 in general; 2 when the whole K extent is at most two stages (1x1 convs with Cin <= 64: the level-0
-// projections and gates), which lets a fourth workgroup share the CU and hide the load latency these short kernels are
-// made of.
+// BK = K elements per stage (64 or 32).  BK = 32 keeps the workgroup at 32 KiB of ring so four of them share one CU:
+// one workgroup's barrier waits, LDS-read latency and epilogue overlap the MFMAs of the others.
+// STAGES = 2 (double buffering, one stage in flight per workgroup): measured better than a 3-stage ring with two stages
+// in flight because the smaller footprint admits a fourth workgroup per CU at BK = 32 (32 KiB ring, 36 KiB epilogue
+// tile) and a second one at BK = 64 -- occupancy hides the load latency better than a deeper ring does (3x3 convs of
+// levels 1-3: -3 %, levels 4-5: -11 %, level-0 1x1: -25 %).
 template <int NT, int BK, int STAGES>
 __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -154,15 +155,16 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   // b rows: nt*32 + lr -> the key only depends on lr because 32 is a multiple of (CPR << RSH)
   const int a_key = (arow >> RSH) & (CPR - 1), b_key = (lr >> RSH) & (CPR - 1);
 
+  constexpr int AHEAD = STAGES - 1;                     // stages in flight: 2 (3-stage ring) or 1 (2-stage ring)
   if (nit > 0) issue(0);
-  if (nit > 1) issue(1);
+  if (AHEAD > 1 && nit > 1) issue(1);
   for (int it = 0; it < nit; ++it) {
-    // stage `it` has landed once at most one younger stage of THIS wave is still in flight; the barrier extends
+    // stage `it` has landed once at most AHEAD-1 younger stages of THIS wave are still in flight; the barrier extends
     // that to every wave's share and also retires everybody's reads of the buffer that is refilled next
-    if (it + 1 < nit) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    if (AHEAD > 1 && it + 1 < nit) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (it + 2 < nit) issue(it + 2);
+    if (it + AHEAD < nit) issue(it + AHEAD);
     const unsigned char* st = smem + (it % STAGES) * STAGE;
     // all operand fragments of the stage first (one LDS round trip), then the MFMAs back to back
     bf16x8 af[KS], bfr[KS][NT];
@@ -424,13 +426,12 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
 
 template <int NT>
 void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
-  // BK = 32 (48 KiB, three workgroups per CU) when there are enough output tiles to co-schedule; the deep levels
+  // BK = 32 (four workgroups per CU) when there are enough output tiles to co-schedule; the deep levels
   // with few tiles go split-K, where the longer BK = 64 stage halves the barrier count (measured: DESIGN.md 4.2)
   const int64_t tiles = cdiv64(M, BM) * cdiv(p.Cout, NT * 32);
   const bool bk64 = (p.dbg & 32) ? true : (p.dbg & 64) ? false : tiles < 256;
-  if (bk64) launch_nt<NT, 64, 3>(p, M, stream);
-  else if (p.taps * cdiv(p.Cin, 32) + cdiv(p.Cinb, 32) <= 2 && !(p.dbg & 128)) launch_nt<NT, 32, 2>(p, M, stream);
-  else launch_nt<NT, 32, 3>(p, M, stream);
+  if (bk64) launch_nt<NT, 64, 2>(p, M, stream);
+  else launch_nt<NT, 32, 2>(p, M, stream);
 }
 
 }  // namespace
