@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
     const int no = hi_cols ? n - p.sel_C : n;           // column of mul / res / out
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+    float gs1 = 0.f, gs2 = 0.f;                         // GroupNorm statistics of this lane's 4 columns over its rows
 #pragma unroll 4
     for (int pass = 0; pass < 32 / RPP; ++pass) {
       const int row = pass * RPP + rsub;
@@ -329,11 +330,29 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
         if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + no); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      if (p.gn_sums) {
+        gs1 += (v.x + v.y) + (v.z + v.w);
+        gs2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
       if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + no) = v;
       if (out16) {
         bf16x4 o;
         o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
         *reinterpret_cast<bf16x4*>(out16 + (size_t)m * p.ldo16 + no) = o;
+      }
+    }
+    if (p.gn_sums) {
+      // the wave's 32 rows lie in one image (HW % 32 == 0); fold rows (lanes L4 apart), then the lanes of one group
+      const int cpg = p.Cout / p.gn_groups, lg = cpg / 4;             // lanes per group within a row segment
+#pragma unroll
+      for (int off = L4; off < 64; off <<= 1) { gs1 += __shfl_xor(gs1, off); gs2 += __shfl_xor(gs2, off); }
+      const int span = lg < L4 ? lg : L4;
+      for (int off = 1; off < span; off <<= 1) { gs1 += __shfl_xor(gs1, off); gs2 += __shfl_xor(gs2, off); }
+      if (rsub == 0 && (c4 % span) == 0) {
+        const int b = (m0 + wave * 32) / HW;
+        double* dst = p.gn_sums + ((size_t)b * p.gn_groups + n / cpg) * 2;
+        atomicAdd(dst, (double)gs1);
+        atomicAdd(dst + 1, (double)gs2);
       }
     }
   }
@@ -436,6 +455,14 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
 
 }  // namespace
 
+bool gemm16_can_fuse_gn(const IGemm& p, int groups) {
+  const int64_t M = (int64_t)p.B * p.H * p.W;
+  const int NTc = p.Cout <= 32 ? 1 : (p.Cout <= 64 ? 2 : 4);
+  const int64_t tiles = cdiv64(M, BM) * cdiv(p.Cout, NTc * 32);
+  return tiles >= 256 /* never split-K */ && ((p.H * p.W) % 32) == 0 && groups > 0 && (p.Cout % groups) == 0 &&
+         ((p.Cout / groups) % 4) == 0 && !p.pk_q && !p.sel_C && p.out;
+}
+
 bool gemm16_supported(const IGemm& p) {
   return p.A16 && p.Wt16 && p.zero16 && (p.Cin % 8) == 0 && (p.lda16 % 8) == 0 && (p.Cout % 4) == 0 &&
          p.store == STORE_NHWC && p.pro_mask == MASK_NONE && !p.scale && p.pro_act == ACT_NONE;
@@ -448,6 +475,10 @@ void launch_gemm16(const IGemm& p, hipStream_t stream) {
     throw std::runtime_error("gemm16: fused qkv packing needs Cout = 192 (4 heads x 16), whole 32-token tiles, plain epilogue");
   if (p.Cinb && !(p.A16b && p.Wt16b && (p.Cinb % 8) == 0 && (p.lda16b % 8) == 0))
     throw std::runtime_error("gemm16: second K segment needs bf16 operands with channel counts that are multiples of 8");
+  if (p.gn_sums) {
+    IGemm q = p; q.gn_sums = nullptr;
+    if (!gemm16_can_fuse_gn(q, p.gn_groups)) throw std::runtime_error("gemm16: GroupNorm statistics cannot be fused for this shape");
+  }
   if (p.sel_C && !(p.Cout == 2 * p.sel_C && (p.sel_C % 64) == 0))
     throw std::runtime_error("gemm16: gate selection needs Cout = 2 * sel_C with sel_C a multiple of 64");
   const int64_t M = (int64_t)p.B * p.H * p.W;

@@ -44,6 +44,10 @@ struct IGemm {
   // [sel_C, 2 sel_C) the high-frequency gate; a row only stores the half that matches its pixel class, at column n mod sel_C
   // (mul / res / out / out16 are indexed with that column; rowscale applies to the high half only)
   int sel_C = 0;
+  // GroupNorm statistics of the OUTPUT tensor accumulated by the epilogue (gemm16.hip, non-split launches): per (sample,
+  // group) sum and sum of squares, fp32 within a wave tile, fp64 atomics across tiles; layout [B][gn_groups][2], zeroed by
+  // the caller.  Saves the separate statistics pass over the tensor (gemm16_can_fuse_gn() says when it applies).
+  double* gn_sums = nullptr; int gn_groups = 0;
   // second K segment (gemm16.hip): a 1x1 operand pair appended after the taps of the first, e.g. the block's 1x1
   // shortcut conv folded into conv_out (out = W_out * S + W_sc * x + (b_out + b_sc)): saves one write + read of `out`
   const void* A16b = nullptr; int lda16b = 0; const void* Wt16b = nullptr; int Cinb = 0;
@@ -53,6 +57,10 @@ struct IGemm {
 void launch_igemm(const IGemm& p, hipStream_t stream);
 bool gemm16_supported(const IGemm& p);
 void launch_gemm16(const IGemm& p, hipStream_t stream);
+bool gemm16_can_fuse_gn(const IGemm& p, int groups);   // p as it will be launched (without gn_sums)
+// fold [B][G][2] fp64 sums (as written by the epilogue above) into per-(b,c) scale / shift
+void launch_gn_from_sums(const double* sums, int B, int HW, int C, int G, const float* gamma, const float* beta, float* scale,
+                         float* shift, hipStream_t stream);
 // fp32 -> bf16 with GroupNorm affine + activation applied once for the consuming conv; optional raw bf16 copy
 void launch_gn_apply16(const float* x, int ldx, int B, int HW, int C, const float* scale, const float* shift, int act,
                        void* out16, int ld16, void* raw16, int ldraw, hipStream_t s);

@@ -338,6 +338,7 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
   }
   int max_splits = gn_splits(H * W, 64);
   p.gn_partial = a.take<double>((size_t)B * 8 * max_splits * 2 + 64);
+  p.gn_sums = a.take<double>((size_t)B * 8 * 2 + 64);
   p.sc1 = a.take<float>((size_t)B * 1024); p.sh1 = a.take<float>((size_t)B * 1024);
   p.sc2 = a.take<float>((size_t)B * 1024); p.sh2 = a.take<float>((size_t)B * 1024);
   p.hidden = a.take<float>((size_t)B * 1024); p.temb = a.take<float>((size_t)B * 256);
@@ -569,9 +570,18 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
                     cin8, s);
   IGemm c1 = g; c1.A16 = p.a16; c1.lda16 = cin8; c1.tb = p.tproj + bw.tproj_off; c1.ldtb = nt_total_;
   c1.out = p.hA; c1.ldo = C;
+  // norm2's statistics come out of conv1's epilogue where the launch is not split-K (levels 0-3 at 256x256)
+  static const bool no_gn_fuse = getenv("DDPMIR_NO_GN_FUSE") != nullptr;
+  IGemm probe = c1; probe.Cout = bw.conv1.cout16; probe.Cin = bw.conv1.cin16; probe.taps = bw.conv1.taps;
+  const bool fuse_gn = !no_gn_fuse && gemm16_can_fuse_gn(probe, gn_groups(C));
+  if (fuse_gn) {
+    DDPMIR_HIP_CHECK(hipMemsetAsync(p.gn_sums, 0, (size_t)B * gn_groups(C) * 2 * sizeof(double), s));
+    c1.gn_sums = p.gn_sums; c1.gn_groups = gn_groups(C);
+  }
   conv16(bw.conv1, c1, s);
   // norm2 -> GELU -> conv2 ; hB also as bf16 for the qkv projection
-  launch_gn_scale_shift(p.hA, C, B, HW, C, gn_groups(C), bw.n2g, bw.n2b, p.gn_partial, p.sc2, p.sh2, s);
+  if (fuse_gn) launch_gn_from_sums(p.gn_sums, B, HW, C, gn_groups(C), bw.n2g, bw.n2b, p.sc2, p.sh2, s);
+  else launch_gn_scale_shift(p.hA, C, B, HW, C, gn_groups(C), bw.n2g, bw.n2b, p.gn_partial, p.sc2, p.sh2, s);
   launch_gn_apply16(p.hA, C, B, HW, C, p.sc2, p.sh2, ACT_GELU, p.a16, C, nullptr, 0, s);
   const bool attn = bw.level >= cfg.attn_min_level;
   IGemm c2 = g; c2.A16 = p.a16; c2.lda16 = C; c2.out = p.hB; c2.ldo = C;

@@ -192,6 +192,38 @@ int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int b
   });
 }
 
+int ddpmir_op_conv_gnstats_bf16(const float* x, int B, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
+                                int ksize, int groups, float* out, double* sums) {
+  return guarded([&] {
+    Dev d;
+    const int taps = ksize * ksize, c8 = round_up(Cin, 8);
+    const size_t M = (size_t)B * H * W;
+    auto bf = [](float f) {
+      unsigned int u;
+      memcpy(&u, &f, 4);
+      return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    };
+    std::vector<unsigned short> wa((size_t)taps * Cout * c8, 0), xa(M * c8, 0);
+    for (int o = 0; o < Cout; ++o)
+      for (int c = 0; c < Cin; ++c)
+        for (int t = 0; t < taps; ++t) wa[((size_t)t * Cout + o) * c8 + c] = bf(w_oihw[((size_t)o * Cin + c) * taps + t]);
+    for (size_t m = 0; m < M; ++m)
+      for (int c = 0; c < Cin; ++c) xa[m * c8 + c] = bf(x[m * Cin + c]);
+    IGemm p;
+    p.B = B; p.H = H; p.W = W; p.Cin = c8; p.Cout = Cout; p.taps = taps; p.bias = d.up(bias, Cout);
+    p.A16 = d.up(xa.data(), xa.size()); p.lda16 = c8; p.Wt16 = d.up(wa.data(), wa.size());
+    p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES);
+    float* o = d.alloc<float>(M * Cout);
+    p.out = o; p.ldo = Cout;
+    if (!gemm16_can_fuse_gn(p, groups)) throw std::runtime_error("conv_gnstats: shape cannot fuse the statistics");
+    double* ds = d.alloc<double>((size_t)B * groups * 2);
+    p.gn_sums = ds; p.gn_groups = groups;
+    launch_gemm16(p, nullptr);
+    d.down(out, o, M * Cout);
+    d.down(sums, ds, (size_t)B * groups * 2);
+  });
+}
+
 int ddpmir_op_conv_dual_bf16(const float* x1, int B, int H, int W, int C1, const float* w1_oihw, int ksize, const float* x2,
                              int C2, const float* w2_oi, const float* bias, int Cout, float* out) {
   return guarded([&] {

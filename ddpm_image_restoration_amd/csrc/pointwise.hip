@@ -474,6 +474,12 @@ void launch_gn_scale_shift(const float* x, int ldx, int B, int HW, int C, int G,
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
+void launch_gn_from_sums(const double* sums, int B, int HW, int C, int G, const float* gamma, const float* beta, float* scale,
+                         float* shift, hipStream_t stream) {
+  hipLaunchKernelGGL(gn_finalize, dim3(G, B), dim3(64), 0, stream, sums, 1, HW, C, round_up(C, 4), G, gamma, beta, scale, shift);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
 void launch_maxpool2(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, hipStream_t s) {
   int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
   if (total <= 0) return;

@@ -19,6 +19,7 @@ _sigs = {
     "ddpmir_op_gn_scale_shift": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "ddpmir_op_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ddpmir_op_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ddpmir_op_conv_gnstats_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "ddpmir_op_conv_dual_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P]),
     "ddpmir_op_qkv_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "ddpmir_op_attention_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
@@ -114,6 +115,19 @@ def attention(qkv, heads, bf16=False):
     fn = lib.ddpmir_op_attention_bf16 if bf16 else lib.ddpmir_op_attention
     _chk(lib, fn(_p(qkv), b, n, c3 // 3, heads, _p(out)), "op_attention")
     return out
+
+
+def conv_gnstats_bf16(x, w, bias, groups):
+    """conv (NHWC in/out) + per-(sample, group) sum / sum-of-squares of the output, from the same launch."""
+    lib = _lib_ops()
+    x, w, bias = _f(x), _f(w), _f(bias)
+    b, h, wd, cin = x.shape
+    cout, _, k, _ = w.shape
+    out = np.empty((b, h, wd, cout), np.float32)
+    sums = np.empty((b, groups, 2), np.float64)
+    _chk(lib, lib.ddpmir_op_conv_gnstats_bf16(_p(x), b, h, wd, cin, _p(w), _p(bias), cout, k, groups, _p(out),
+                                              sums.ctypes.data_as(C.c_void_p)), "op_conv_gnstats")
+    return out, sums
 
 
 def conv_dual_bf16(x1, w1, x2, w2, bias):

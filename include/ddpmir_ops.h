@@ -41,6 +41,10 @@ int ddpmir_op_gn_scale_shift(const float* x, int B, int HW, int C, int G, const 
 int ddpmir_op_attention(const float* qkv, int B, int N, int C, int heads, float* out);
 /* same through the bf16 matrix-core kernel (fp32 in/out, bf16 operands, fp32 accumulation) */
 int ddpmir_op_attention_bf16(const float* qkv, int B, int N, int C, int heads, float* out);
+/* conv through the DMA GEMM whose epilogue also accumulates the GroupNorm statistics of its OUTPUT (the next layer's
+ * nn.GroupNorm, webp_inference.py:290): sums [B][groups][2] = (sum, sum of squares) per sample and group. */
+int ddpmir_op_conv_gnstats_bf16(const float* x, int B, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
+                                int ksize, int groups, float* out, double* sums);
 /* out = conv_kxk(x1, w1) + conv_1x1(x2, w2) + bias in ONE DMA-GEMM launch (second K segment): conv_out with the block's
  * 1x1 shortcut folded in (webp_inference.py:326-327).  x1 [B,H,W,C1], x2 [B,H,W,C2], out [B,H,W,Cout]. */
 int ddpmir_op_conv_dual_bf16(const float* x1, int B, int H, int W, int C1, const float* w1_oihw, int ksize, const float* x2,

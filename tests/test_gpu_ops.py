@@ -101,6 +101,23 @@ def test_conv_bf16_dma_second_k_segment(ops, B, H, W, C1, C2, Cout):
     close(nchw(got), ref, 4e-5)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,G", [(2, 128, 128, 64, 64, 3, 8), (8, 64, 64, 32, 128, 1, 8), (8, 64, 64, 64, 256, 3, 8),
+                                                (2, 128, 128, 8, 32, 3, 8), (16, 64, 32, 16, 512, 1, 8)])
+def test_conv_bf16_dma_fused_groupnorm_statistics(ops, B, H, W, Cin, Cout, k, G):
+    """the epilogue's per-(sample, group) sum / sum of squares must be the statistics of the tensor it stored."""
+    x = rnd(B, Cin, H, W, seed=50)
+    w = rnd(Cout, Cin, k, k, seed=51, scale=1.0 / np.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=52) + 0.5
+    out, sums = ops.conv_gnstats_bf16(nhwc(x), w, b, G)
+    o = out.astype(np.float64).reshape(B, H * W, G, Cout // G)
+    want = np.stack([o.sum(axis=(1, 3)), (o * o).sum(axis=(1, 3))], axis=-1)
+    assert np.allclose(sums, want, rtol=2e-5, atol=1e-2), np.abs(sums - want).max()
+    n = H * W * (Cout // G)                                  # what nn.GroupNorm derives from them
+    mean, mean_w = sums[..., 0] / n, want[..., 0] / n
+    var, var_w = sums[..., 1] / n - mean ** 2, want[..., 1] / n - mean_w ** 2
+    assert np.abs(mean - mean_w).max() < 1e-5 and np.abs(var - var_w).max() < 1e-5
+
+
 def test_conv_bf16_fused_prologue_epilogue(ops):
     B, H, W, C, Co = 2, 16, 16, 64, 128
     x = rnd(B, C, H, W, seed=4, scale=2.0) + 0.5
