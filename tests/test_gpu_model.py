@@ -66,6 +66,10 @@ def test_forward_bf16_mode(name, arch, golden, models):
     y = m(tt(g["fwd64_x"]), tt(g["fwd64_t"]), tt(g["fwd64_t"])).cpu().numpy()
     err = np.abs(y - g["fwd64_y"])
     assert err.max() < 2e-2 and err.mean() < 2e-3, (err.max(), err.mean())
+    # non-square 96x64: level maps 96x64 ... 3x2 (ragged GEMM tiles, maps smaller than a DCT block, 6-token attention)
+    y = m(tt(g["fwd96_x"]), tt(g["fwd64_t"]), None).cpu().numpy()
+    err = np.abs(y - g["fwd96_y"])
+    assert err.max() < 2e-2 and err.mean() < 2e-3, (err.max(), err.mean())
 
 
 @pytest.mark.parametrize("name,arch", ARCHS)
