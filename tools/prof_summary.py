@@ -1,6 +1,7 @@
 import csv, sys, collections, glob
 d = sys.argv[1]
-t = glob.glob(d + "/*/*kernel_trace.csv")[0]
+import os
+t = max(glob.glob(d + "/*/*kernel_trace.csv"), key=os.path.getmtime)   # newest run in the directory
 rows = list(csv.DictReader(open(t)))
 n_fwd = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 agg = collections.defaultdict(lambda: [0, 0.0])
