@@ -14,6 +14,7 @@
 // read applies the same XOR (rule: linear destination + permuted source + permuted read).  Rows outside the image (3x3 halo),
 // rows past M / Cout and channel chunks past Cin are fetched from a 16-byte zero page.
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -49,11 +50,11 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = p.B * p.H * p.W, HW = p.H * p.W;
   // XCD-aware placement: consecutive M tiles (which share 3x3 halo rows) run on the same XCD / L2
-  // Weight-bound shapes (few M tiles, BK = 64 variant): blockIdx.x is the N tile instead, so the M tiles that stream the
+  // Weight-bound shapes (few M tiles, p.nmajor): blockIdx.x is the N tile instead, so the M tiles that stream the
   // SAME weight slice get workgroup ids a multiple of gridDim.x apart = the same XCD, and the slice is fetched into one
   // L2 instead of eight (the activations are small enough to sit in every L2).
   int bx, by;
-  if (BK == 64) { bx = blockIdx.y; by = blockIdx.x; }
+  if (p.nmajor) { bx = blockIdx.y; by = blockIdx.x; }
   else {
     bx = blockIdx.x; by = blockIdx.y;
     if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
@@ -433,14 +434,16 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   if (nsplit > 1 && !(p.res && p.res == p.out))
     hipLaunchKernelGGL(zero_rows16_k, dim3((unsigned)std::min<int64_t>(cdiv64(M * (p.Cout / 4), 256), 2048)), dim3(256), 0,
                        stream, p.out, p.ldo, M, p.Cout / 4);
+  IGemm q = p;
+  q.nmajor = gx * gy < 256;                             // few M tiles: the weight stream is what to keep inside one L2
+  const dim3 grid = q.nmajor ? dim3(gy, gx, nsplit) : dim3(gx, gy, nsplit);
   if (nsplit > 1 && p.out16) {
-    IGemm q = p;
     q.out16 = nullptr;
-    hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES>), BK == 64 ? dim3(gy, gx, nsplit) : dim3(gx, gy, nsplit), dim3(256), LDS, stream, q);
+    hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES>), grid, dim3(256), LDS, stream, q);
     launch_gn_apply16(p.out, p.ldo, p.B, p.H * p.W, p.Cout, nullptr, nullptr, ACT_NONE, p.out16, p.ldo16, nullptr, 0, stream);
     return;
   }
-  hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES>), BK == 64 ? dim3(gy, gx, nsplit) : dim3(gx, gy, nsplit), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES>), grid, dim3(256), LDS, stream, q);
 }
 
 template <int NT>
@@ -448,7 +451,12 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
   // BK = 32 (four workgroups per CU) when there are enough output tiles to co-schedule; the deep levels
   // with few tiles go split-K, where the longer BK = 64 stage halves the barrier count (measured: DESIGN.md 4.2)
   const int64_t tiles = cdiv64(M, BM) * cdiv(p.Cout, NT * 32);
-  const bool bk64 = (p.dbg & 32) ? true : (p.dbg & 64) ? false : tiles < 256;
+  // ... and so does a long K loop with enough work per barrier: 3x3 convs with Cout <= 64 or K >= 2048 measured 5-15 %
+  // faster at BK = 64 / two workgroups per CU than at BK = 32 / four (tools/gemm_inventory.py), 1x1 and short-K the reverse
+  const int ktot = p.taps * p.Cin + p.Cinb;
+  static const bool no_longk = getenv("DDPMIR_GEMM_NO_LONGK") != nullptr;   // A/B switch
+  const bool longk = !no_longk && p.taps == 9 && (NT <= 2 || ktot >= 2048);
+  const bool bk64 = (p.dbg & 32) ? true : (p.dbg & 64) ? false : (tiles < 256 || longk);
   if (bk64) launch_nt<NT, 64, 2>(p, M, stream);
   else launch_nt<NT, 32, 2>(p, M, stream);
 }

@@ -52,6 +52,7 @@ struct IGemm {
   // shortcut conv folded into conv_out (out = W_out * S + W_sc * x + (b_out + b_sc)): saves one write + read of `out`
   const void* A16b = nullptr; int lda16b = 0; const void* Wt16b = nullptr; int Cinb = 0;
   void* pk_q = nullptr; void* pk_kv = nullptr; float* pk_kmax = nullptr; int pk_nt = 0; float pk_qscale = 0.f;
+  int nmajor = 0;   // set by the launcher: blockIdx.x is the N tile (weight-bound shapes), see gemm16.hip
   int dbg = 0;   // timing experiments only: 1 skip A loads, 2 skip B loads, 4 skip MFMA, 8 skip stores, 16 skip LDS writes
 };
 void launch_igemm(const IGemm& p, hipStream_t stream);
