@@ -479,12 +479,12 @@ static_assert(AttnGeom<16>::TILE_BYTES == ATTN16_TILE_BYTES && AttnGeom<16>::KT_
               AttnGeom<16>::RV == ATTN16_RV && AttnGeom<16>::DP == 16, "AttnPack16 geometry out of sync");
 
 bool attention_bf16_prepack_supported(int N, int C, int heads) {
-  return C == 64 && heads == 4 && (N % 32) == 0 && N >= 64;
+  return heads == 4 && (C == 64 || C == 128) && (N % 32) == 0 && N >= 64;
 }
 
-AttnPack16 attention_bf16_pack_targets(int B, int N, int C, int heads, void* ws) {   // same carve-up as run_flash<16>
-  using G = AttnGeom<16>;
-  (void)C;
+template <int D>
+static AttnPack16 pack_targets_for(int B, int N, int heads, void* ws) {   // same carve-up as run_flash<D>
+  using G = AttnGeom<D>;
   const size_t NT = (N + 31) / 32, BH = (size_t)B * heads;
   const size_t q_bytes = (BH * NT * 32 * G::DP * 2 + 255) & ~size_t(255);
   const size_t kv_bytes = (BH * NT * G::TILE_BYTES + 255) & ~size_t(255);
@@ -493,8 +493,16 @@ AttnPack16 attention_bf16_pack_targets(int B, int N, int C, int heads, void* ws)
   t.kv = static_cast<unsigned char*>(ws) + q_bytes;
   t.kmax = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + q_bytes + kv_bytes);
   t.ntiles = (int)NT;
-  t.qscale = 1.44269504088896340736f / sqrtf(16.0f);
+  t.qscale = 1.44269504088896340736f / sqrtf((float)D);
+  t.D = D;
   return t;
+}
+
+static_assert(AttnGeom<32>::TILE_BYTES == 4096 && AttnGeom<32>::KT_BYTES == 2048 && AttnGeom<32>::RV == 32 && AttnGeom<32>::DP == 32,
+              "head_dim-32 pack geometry out of sync with gemm16.hip");
+
+AttnPack16 attention_bf16_pack_targets(int B, int N, int C, int heads, void* ws) {
+  return C / heads == 32 ? pack_targets_for<32>(B, N, heads, ws) : pack_targets_for<16>(B, N, heads, ws);
 }
 
 size_t attention_bf16_workspace(int B, int N, int C, int heads) {

@@ -222,12 +222,16 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   for (int h = 0; h < NT / HN; ++h) {
     if constexpr (NT == 4) {
       if (p.pk_q) {   // fused qkv projection: this 32-token x 64-column tile is Q, K or V of one 32-key attention tile
+        // 4 heads of head_dim D = 16 or 32 (C = 4 D); a 64-column pass holds 64/D heads = NCH 16-deep chunks each
+        const int D = p.pk_D, C = 4 * D, NCH = D >> 4, HPP = 64 / D;
         const int mrow0 = m0 + wave * 32, nb = n0 + h * BNH;
-        if (mrow0 >= M || nb >= 192) continue;
+        if (mrow0 >= M || nb >= 3 * C) continue;
         const int b = mrow0 / HW, tile = (mrow0 - b * HW) >> 5;
-        if (nb < 128) {
+        const int region = nb / C, head0 = (nb - region * C) / D;      // 0 = Q, 1 = K, 2 = V
+        const int kt_bytes = NCH * 1024, rv = D == 16 ? 17 : 32, tile_bytes = kt_bytes + 4 * rv * 16;
+        if (region < 2) {
           // Q / K: row-major tile [token][64 + 4], bias (and the softmax scale for Q) folded in on the way
-          const float mulv = nb == 0 ? p.pk_qscale : 1.0f;
+          const float mulv = region == 0 ? p.pk_qscale : 1.0f;
 #pragma unroll
           for (int q = 0; q < HN; ++q) {
             const float bcol = p.bias[nb + q * 32 + lr];
@@ -235,23 +239,26 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
             for (int r = 0; r < 16; ++r)
               ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + q * 32 + lr] = (acc[h * HN + q][r] + bcol) * mulv;
           }
-          // lane (hh = lane >> 5, token = lane & 31) owns components 8hh..8hh+7 of every head
+          // lane (hh = lane >> 5, token = lane & 31) owns components 16c + 8hh .. +7 of chunk c of every head
           const int tok = lane & 31, hh = lane >> 5;
+          for (int hp = 0; hp < HPP; ++hp) {
+            const size_t bh_tile = (size_t)(b * 4 + head0 + hp) * p.pk_nt + tile;
+            float nk = 0.f;
+            for (int c = 0; c < NCH; ++c) {
+              const float* src = ct + tok * BNP + hp * D + 16 * c + hh * 8;
+              const float4 a = *reinterpret_cast<const float4*>(src), e = *reinterpret_cast<const float4*>(src + 4);
+              bf16x8 v;
+              v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+              v[4] = (__bf16)e.x; v[5] = (__bf16)e.y; v[6] = (__bf16)e.z; v[7] = (__bf16)e.w;
+              if (region == 0) {         // Q[bh][token][D]
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.pk_q) + (bh_tile * 32 + tok) * D + 16 * c + hh * 8) = v;
+              } else {                   // K image: chunk c, lane l = hh*32 + key at byte c*1024 + l*16
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(p.pk_kv) + bh_tile * tile_bytes + c * 1024 + lane * 16) = v;
 #pragma unroll
-          for (int hd = 0; hd < 4; ++hd) {
-            const float* src = ct + tok * BNP + hd * 16 + hh * 8;
-            const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
-            bf16x8 v;
-            v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-            v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
-            const size_t bh_tile = (size_t)(b * 4 + hd) * p.pk_nt + tile;
-            if (nb == 0) {             // Q[bh][token][16]: 32 B per token and head
-              *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.pk_q) + (bh_tile * 32 + tok) * 16 + hh * 8) = v;
-            } else {                   // K image: lane l = hh*32 + key at byte l*16; tile max of |k| on the rounded values
-              *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(p.pk_kv) + bh_tile * ATTN16_TILE_BYTES + lane * 16) = v;
-              float nk = 0.f;
-#pragma unroll
-              for (int j2 = 0; j2 < 8; ++j2) { const float f = (float)v[j2]; nk = fmaf(f, f, nk); }
+                for (int j2 = 0; j2 < 8; ++j2) { const float f = (float)v[j2]; nk = fmaf(f, f, nk); }
+              }
+            }
+            if (region == 1) {           // tile max of |k| on the rounded values (bound of any score of this tile)
               nk += __shfl_xor(nk, 32);
 #pragma unroll
               for (int off = 16; off > 0; off >>= 1) nk = fmaxf(nk, __shfl_xor(nk, off));
@@ -270,26 +277,26 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
                   make_float4(acc[h * HN + q][4 * g4] + bcol, acc[h * HN + q][4 * g4 + 1] + bcol,
                               acc[h * HN + q][4 * g4 + 2] + bcol, acc[h * HN + q][4 * g4 + 3] + bcol);
           }
-          // V^T image: slab (s, hh), row d, slot j = key (j&3) + 8*(2s + (j>>2)) + 4hh; 4 heads x 4 slabs x 16 rows = 4 per lane
+          // V^T image: slab (s, hh), row d, slot j = key (j&3) + 8*(2s + (j>>2)) + 4hh; 64 columns x 4 slabs = 4 items per lane
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
-            const int item = it * 64 + lane, hd = item >> 6, slab = (item >> 4) & 3, row = item & 15;
-            const int sI = slab >> 1, hh = slab & 1;
-            const float* src = ct + (hd * 16 + row) * TP + 16 * sI + 4 * hh;
-            const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 8);
+            const int item = it * 64 + lane, col = item & 63, slab = item >> 6;      // col = head-in-pass * D + row
+            const int hp = col / D, row = col - hp * D, sI = slab >> 1, hh = slab & 1;
+            const float* src = ct + col * TP + 16 * sI + 4 * hh;
+            const float4 a = *reinterpret_cast<const float4*>(src), e = *reinterpret_cast<const float4*>(src + 8);
             bf16x8 v;
             v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-            v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
-            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * 4 + hd) * p.pk_nt + tile) * ATTN16_TILE_BYTES + ATTN16_KT_BYTES;
-            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * ATTN16_RV * 16 + row * 16) = v;
+            v[4] = (__bf16)e.x; v[5] = (__bf16)e.y; v[6] = (__bf16)e.z; v[7] = (__bf16)e.w;
+            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * 4 + head0 + hp) * p.pk_nt + tile) * tile_bytes + kt_bytes;
+            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * rv * 16 + row * 16) = v;
           }
-          if (lane < 16) {             // the ones row (softmax denominator): row 16 of each (head, slab)
+          if (D == 16 && lane < 16) {   // the ones row (softmax denominator): row 16 of each (head, slab)
             bf16x8 one;
 #pragma unroll
             for (int j2 = 0; j2 < 8; ++j2) one[j2] = (__bf16)1.0f;
             const int hd = lane >> 2, slab = lane & 3;
-            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * 4 + hd) * p.pk_nt + tile) * ATTN16_TILE_BYTES + ATTN16_KT_BYTES;
-            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * ATTN16_RV * 16 + 16 * 16) = one;
+            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * 4 + hd) * p.pk_nt + tile) * tile_bytes + kt_bytes;
+            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * rv * 16 + 16 * 16) = one;
           }
         }
         continue;
@@ -478,9 +485,9 @@ bool gemm16_supported(const IGemm& p) {
 
 void launch_gemm16(const IGemm& p, hipStream_t stream) {
   if (!gemm16_supported(p)) throw std::runtime_error("gemm16: unsupported operand layout");
-  if (p.pk_q && !(p.Cout == 192 && p.taps == 1 && p.bias && p.pk_kv && p.pk_kmax && ((p.H * p.W) % 32) == 0 &&
-                  p.pk_nt * 32 == p.H * p.W && p.epi_act == ACT_NONE && !p.mul && !p.res && !p.tb))
-    throw std::runtime_error("gemm16: fused qkv packing needs Cout = 192 (4 heads x 16), whole 32-token tiles, plain epilogue");
+  if (p.pk_q && !((p.pk_D == 16 || p.pk_D == 32) && p.Cout == 12 * p.pk_D && p.taps == 1 && p.bias && p.pk_kv && p.pk_kmax &&
+                  ((p.H * p.W) % 32) == 0 && p.pk_nt * 32 == p.H * p.W && p.epi_act == ACT_NONE && !p.mul && !p.res && !p.tb))
+    throw std::runtime_error("gemm16: fused qkv packing needs 4 heads of head_dim 16 or 32, whole 32-token tiles, plain epilogue");
   if (p.Cinb && !(p.A16b && p.Wt16b && (p.Cinb % 8) == 0 && (p.lda16b % 8) == 0))
     throw std::runtime_error("gemm16: second K segment needs bf16 operands with channel counts that are multiples of 8");
   if (p.gn_sums) {

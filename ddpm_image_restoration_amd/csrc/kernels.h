@@ -38,7 +38,7 @@ struct IGemm {
   const void* A16 = nullptr; int lda16 = 0;
   const void* zero16 = nullptr;               // GEMM16_ZERO_BYTES of zeros in device memory (halo / tail source)
   void* out16 = nullptr; int ldo16 = 0;       // optional bf16 copy of the epilogue result (out may then be null)
-  // qkv projection fused with the attention operand packing (head_dim 16, 4 heads, C = 64: gemm16.hip epilogue writes
+  // qkv projection fused with the attention operand packing (4 heads of head_dim 16 or 32: gemm16.hip epilogue writes
   // the Q / K / V^T images of attention_bf16.hip directly instead of an fp32 [M][192] tensor); see AttnPack16
   // per-pixel gate selection (frequency block, gemm16.hip): Cout = 2*sel_C; columns [0, sel_C) are the low-frequency gate,
   // [sel_C, 2 sel_C) the high-frequency gate; a row only stores the half that matches its pixel class, at column n mod sel_C
@@ -51,7 +51,7 @@ struct IGemm {
   // second K segment (gemm16.hip): a 1x1 operand pair appended after the taps of the first, e.g. the block's 1x1
   // shortcut conv folded into conv_out (out = W_out * S + W_sc * x + (b_out + b_sc)): saves one write + read of `out`
   const void* A16b = nullptr; int lda16b = 0; const void* Wt16b = nullptr; int Cinb = 0;
-  void* pk_q = nullptr; void* pk_kv = nullptr; float* pk_kmax = nullptr; int pk_nt = 0; float pk_qscale = 0.f;
+  void* pk_q = nullptr; void* pk_kv = nullptr; float* pk_kmax = nullptr; int pk_nt = 0; float pk_qscale = 0.f; int pk_D = 16;
   int nmajor = 0;   // set by the launcher: blockIdx.x is the N tile (weight-bound shapes), see gemm16.hip
   int dbg = 0;   // timing experiments only: 1 skip A loads, 2 skip B loads, 4 skip MFMA, 8 skip stores, 16 skip LDS writes
 };
@@ -77,7 +77,7 @@ bool attention_bf16_supported(int N, int C, int heads);
 // Operand images of the head_dim-16 attention kernel inside `workspace`, for producers that write them directly
 // (the fused qkv projection).  Tile = 32 keys: K image 1024 B + V^T image (2 x 2 slabs of 17 rows x 16 B).
 constexpr int ATTN16_KT_BYTES = 1024, ATTN16_RV = 17, ATTN16_TILE_BYTES = ATTN16_KT_BYTES + 4 * ATTN16_RV * 16;
-struct AttnPack16 { void* q; void* kv; float* kmax; int ntiles; float qscale; };
+struct AttnPack16 { void* q; void* kv; float* kmax; int ntiles; float qscale; int D; };
 bool attention_bf16_prepack_supported(int N, int C, int heads);
 AttnPack16 attention_bf16_pack_targets(int B, int N, int C, int heads, void* workspace);
 size_t attention_bf16_workspace(int B, int N, int C, int heads);
