@@ -379,7 +379,9 @@ __global__ void zero_rows16_k(float* out, int ldo, int64_t M, int C4) {
 // (x*scale[b][c] + shift[b][c], then act); optionally also a raw bf16 copy (input of the 1x1 shortcut conv).
 __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C, int Cs, const float* __restrict__ scale,
                              const float* __restrict__ shift, int act, __bf16* __restrict__ out, int ld16,
-                             __bf16* __restrict__ raw, int ldraw, int64_t M) {
+                             __bf16* __restrict__ raw, int ldraw, int64_t M, double* __restrict__ zero, int nzero) {
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0.0;
   const int C8 = (C + 7) / 8;
   const int64_t total = M * C8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -505,13 +507,13 @@ void launch_gemm16(const IGemm& p, hipStream_t stream) {
 }
 
 void launch_gn_apply16(const float* x, int ldx, int B, int HW, int C, const float* scale, const float* shift, int act,
-                       void* out16, int ld16, void* raw16, int ldraw, hipStream_t s) {
+                       void* out16, int ld16, void* raw16, int ldraw, hipStream_t s, double* zero, int nzero) {
   const int64_t M = (int64_t)B * HW;
   const int64_t total = M * ((C + 7) / 8);
   int64_t g = (total + 255) / 256;
   g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
   hipLaunchKernelGGL(gn_apply16_k, dim3((unsigned)g), dim3(256), 0, s, x, ldx, HW, C, round_up(C, 4), scale, shift, act,
-                     reinterpret_cast<__bf16*>(out16), ld16, reinterpret_cast<__bf16*>(raw16), ldraw, M);
+                     reinterpret_cast<__bf16*>(out16), ld16, reinterpret_cast<__bf16*>(raw16), ldraw, M, zero, nzero);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

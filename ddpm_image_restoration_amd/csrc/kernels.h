@@ -63,8 +63,9 @@ bool gemm16_can_fuse_gn(const IGemm& p, int groups);   // p as it will be launch
 void launch_gn_from_sums(const double* sums, int B, int HW, int C, int G, const float* gamma, const float* beta, float* scale,
                          float* shift, hipStream_t stream);
 // fp32 -> bf16 with GroupNorm affine + activation applied once for the consuming conv; optional raw bf16 copy
+// (zero/nzero: optionally clears a small fp64 accumulator, e.g. IGemm::gn_sums of the GEMM that consumes this operand)
 void launch_gn_apply16(const float* x, int ldx, int B, int HW, int C, const float* scale, const float* shift, int act,
-                       void* out16, int ld16, void* raw16, int ldraw, hipStream_t s);
+                       void* out16, int ld16, void* raw16, int ldraw, hipStream_t s, double* zero = nullptr, int nzero = 0);
 
 // ------------------------------------------------------------------------------------------------ attention
 // softmax(Q K^T / sqrt(d)) V per (batch, head); qkv is [B][N][3C] (q | k | v, heads contiguous in C),
