@@ -87,7 +87,7 @@ def main():
     if env.world != args.gpus:
         if env.rank == 0:
             print(f"warning: WORLD_SIZE={env.world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
-    dev = torch.device("cuda", env.local_rank)
+    dev = torch.device("cuda", env.local_rank % max(1, torch.cuda.device_count()))   # (modulo: single-GPU rehearsal)
     torch.cuda.set_device(dev)
 
     B, R, q = args.batch, args.size, args.quality

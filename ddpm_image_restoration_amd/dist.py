@@ -29,7 +29,8 @@ def init_from_env(backend: str | None = None) -> DistEnv:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # DDPMIR_DIST_BACKEND=gloo: rehearse the multi-rank path with several ranks sharing ONE GPU (RCCL refuses that)
+        backend = os.environ.get("DDPMIR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
