@@ -186,25 +186,18 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   if ((p.dbg & 8) && acc[0][0] != 12345.f) return;
   const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE || p.sel_C;
   const bool atomic = nsplit > 1;
-  const bool lead = sk == 0;
   if (atomic) {
-    // split-K partial sums (linear epilogue only): 256-byte row segments per wave instruction
+    // split-K: raw partial sums to the workspace slice of this split (128-byte row segments per wave instruction); the
+    // linear epilogue runs in splitk_reduce_k, which adds the slices in a fixed order
+    float* ws = p.splitk_ws + (size_t)sk * M * p.Cout;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m >= M) continue;
-      const int b = p.tb ? m / HW : 0;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int n = n0 + nt * 32 + lr;
-        if (n >= p.Cout) continue;
-        float v = acc[nt][r];
-        if (lead) {
-          if (p.bias) v += p.bias[n];
-          if (p.tb) v += p.tb[(size_t)b * p.ldtb + n];
-          if (p.res && p.res != p.out) v += p.res[(size_t)m * p.ldres + n];
-        }
-        atomicAdd(&p.out[(size_t)m * p.ldo + n], v);
+        if (n < p.Cout) ws[(size_t)m * p.Cout + n] = acc[nt][r];
       }
     }
     return;
@@ -366,12 +359,31 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   }
 }
 
-__global__ void zero_rows16_k(float* out, int ldo, int64_t M, int C4) {
+// out[m][n] = sum_s ws[s][m][n] (s ascending) + bias + time bias + residual, optional bf16 copy
+__global__ void splitk_reduce_k(const IGemm p, int nsplit, int64_t M, int HW) {
+  const int C4 = p.Cout / 4;
   const int64_t total = M * C4;
+  __bf16* out16 = reinterpret_cast<__bf16*>(p.out16);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t m = i / C4;
-    int c4 = (int)(i - m * C4);
-    *reinterpret_cast<float4*>(out + m * ldo + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t m = i / C4;
+    const int n = (int)(i - m * C4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(p.splitk_ws + (size_t)m * p.Cout + n);
+    for (int sidx = 1; sidx < nsplit; ++sidx) {
+      const float4 t = *reinterpret_cast<const float4*>(p.splitk_ws + ((size_t)sidx * M + m) * p.Cout + n);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (p.tb) {
+      const float4 t = *reinterpret_cast<const float4*>(p.tb + (size_t)(m / HW) * p.ldtb + n);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (p.res) { const float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + n) = v;
+    if (out16) {
+      bf16x4 o;
+      o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+      *reinterpret_cast<bf16x4*>(out16 + (size_t)m * p.ldo16 + n) = o;
+    }
   }
 }
 
@@ -433,26 +445,20 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
   const int nit = p.taps * cdiv(p.Cin, BK) + cdiv(p.Cinb, BK);
   int nsplit = 1;
-  // (a bf16 copy of the result does not prevent split-K: it is converted from the fp32 sums afterwards)
-  const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && p.out && !p.pk_q && !p.sel_C &&
-                      (!p.out16 || (p.Cout % 8) == 0) && (!p.res || p.res != p.out || p.ldres == p.ldo);
+  const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && (p.out || p.out16) && !p.pk_q &&
+                      !p.sel_C && !p.gn_sums && p.splitk_ws;
   if (linear && gx * gy < 256 && nit >= 8 * (64 / BK)) {
     nsplit = std::min(std::min(16, nit / (4 * (64 / BK))), cdiv(512, gx * gy));
+    nsplit = std::min<int64_t>(nsplit, (int64_t)(p.splitk_ws_bytes / ((size_t)M * p.Cout * sizeof(float))));
     if (nsplit < 1) nsplit = 1;
   }
-  if (nsplit > 1 && !(p.res && p.res == p.out))
-    hipLaunchKernelGGL(zero_rows16_k, dim3((unsigned)std::min<int64_t>(cdiv64(M * (p.Cout / 4), 256), 2048)), dim3(256), 0,
-                       stream, p.out, p.ldo, M, p.Cout / 4);
   IGemm q = p;
   q.nmajor = gx * gy < 256;                             // few M tiles: the weight stream is what to keep inside one L2
   const dim3 grid = q.nmajor ? dim3(gy, gx, nsplit) : dim3(gx, gy, nsplit);
-  if (nsplit > 1 && p.out16) {
-    q.out16 = nullptr;
-    hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES>), grid, dim3(256), LDS, stream, q);
-    launch_gn_apply16(p.out, p.ldo, p.B, p.H * p.W, p.Cout, nullptr, nullptr, ACT_NONE, p.out16, p.ldo16, nullptr, 0, stream);
-    return;
-  }
   hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES>), grid, dim3(256), LDS, stream, q);
+  if (nsplit > 1)
+    hipLaunchKernelGGL(splitk_reduce_k, dim3((unsigned)std::min<int64_t>(cdiv64(M * (p.Cout / 4), 256), 2048)), dim3(256), 0, stream,
+                       p, nsplit, M, p.H * p.W);
 }
 
 template <int NT>

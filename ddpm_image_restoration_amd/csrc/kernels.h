@@ -12,6 +12,7 @@ namespace ddpmir {
 // The zero page the DMA GEMM reads halo / tail chunks from.  64 KiB, not 16 B: every lane of every workgroup reads its
 // own 16-byte slot, so border-heavy shapes (8x8 maps: 30 % of the A loads) do not all hammer one L2 channel.
 constexpr int GEMM16_ZERO_BYTES = 65536;
+constexpr size_t GEMM16_SPLITK_WS_BYTES = size_t(64) << 20;   // what the model / op wrappers reserve for split-K partials
 
 struct IGemm {
   // input
@@ -52,6 +53,9 @@ struct IGemm {
   // shortcut conv folded into conv_out (out = W_out * S + W_sc * x + (b_out + b_sc)): saves one write + read of `out`
   const void* A16b = nullptr; int lda16b = 0; const void* Wt16b = nullptr; int Cinb = 0;
   void* pk_q = nullptr; void* pk_kv = nullptr; float* pk_kmax = nullptr; int pk_nt = 0; float pk_qscale = 0.f; int pk_D = 16;
+  // split-K partial sums [nsplit][M][Cout] fp32 (gemm16.hip): written by the splits, folded in fixed order by a second
+  // kernel together with bias / time bias / residual / bf16 copy -> bf16 mode is bit-reproducible (no float atomics)
+  float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;
   int nmajor = 0;   // set by the launcher: blockIdx.x is the N tile (weight-bound shapes), see gemm16.hip
   int dbg = 0;   // timing experiments only: 1 skip A loads, 2 skip B loads, 4 skip MFMA, 8 skip stores, 16 skip LDS writes
 };

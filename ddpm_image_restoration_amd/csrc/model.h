@@ -121,6 +121,7 @@ class Context {
     unsigned short *a16 = nullptr, *x16 = nullptr, *hB16 = nullptr, *att16 = nullptr, *xdl16 = nullptr, *xdh16 = nullptr,
                    *hid16 = nullptr, *S16 = nullptr;
     unsigned char* zero16 = nullptr;
+    float* splitk_ws = nullptr;
     double* gn_partial = nullptr;
     double* gn_sums = nullptr;   // [B][8][2] statistics accumulated by a GEMM epilogue (conv1 -> norm2)
     float *sc1 = nullptr, *sh1 = nullptr, *sc2 = nullptr, *sh2 = nullptr;

@@ -335,6 +335,7 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
     p.hB16 = a.take<unsigned short>(mc); p.att16 = a.take<unsigned short>(mc); p.xdl16 = a.take<unsigned short>(mc);
     p.xdh16 = a.take<unsigned short>(mc); p.hid16 = a.take<unsigned short>(mc); p.S16 = a.take<unsigned short>(mc);
     p.zero16 = a.take<unsigned char>(GEMM16_ZERO_BYTES);
+    p.splitk_ws = a.take<float>(GEMM16_SPLITK_WS_BYTES / sizeof(float));
   }
   int max_splits = gn_splits(H * W, 64);
   p.gn_partial = a.take<double>((size_t)B * 8 * max_splits * 2 + 64);
@@ -549,7 +550,7 @@ void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
 
 void Context::conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override) {
   p.Wt = nullptr; p.Wt16 = cw.w16; p.bias = bias_override ? bias_override : cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
-  p.zero16 = plan_.zero16;
+  p.zero16 = plan_.zero16; p.splitk_ws = plan_.splitk_ws; p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
   if (gemm16_supported(p)) launch_gemm16(p, s);
   else throw std::logic_error("conv16: operand layout not supported by the DMA GEMM");
 }

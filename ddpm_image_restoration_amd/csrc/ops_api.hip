@@ -97,7 +97,7 @@ int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_
       launch_gn_apply16(dx, cinp, B, H * W, cinp, dsc, dsh, pro_act, a16, cin8, nullptr, 0, nullptr);
       IGemm p;
       p.B = B; p.H = H; p.W = W; p.Cin = cin8; p.Cout = Cout; p.taps = taps; p.bias = d.up(bias, Cout);
-      p.A16 = a16; p.lda16 = cin8; p.Wt16 = d.up(w8.data(), w8.size()); p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES);
+      p.A16 = a16; p.lda16 = cin8; p.Wt16 = d.up(w8.data(), w8.size()); p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); p.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
       p.tb = d.up(tb, (size_t)B * Cout); p.ldtb = Cout; p.epi_act = epi_act; p.bs = bs; p.low = low;
       // gate-select mode: mul / res / out have Cout/2 columns (see IGemm::sel_C)
       const int Co = g_sel ? g_sel : Cout;
@@ -165,7 +165,7 @@ int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int b
       if (Cin % 8) throw std::runtime_error("gemm16 timing needs Cin % 8 == 0");
       unsigned short* a16 = d.alloc<unsigned short>(M * Cin + 8);
       launch_gn_apply16(x, Cin, B, H * W, Cin, nullptr, nullptr, ACT_NONE, a16, Cin, nullptr, 0, nullptr);
-      p.A16 = a16; p.lda16 = Cin; p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES);
+      p.A16 = a16; p.lda16 = Cin; p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); p.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
       if (gelu_norm) { p.out16 = d.alloc<unsigned short>(M * Cout + 8); p.ldo16 = Cout; }
       gelu_norm = 0;
     }
@@ -212,7 +212,7 @@ int ddpmir_op_conv_gnstats_bf16(const float* x, int B, int H, int W, int Cin, co
     IGemm p;
     p.B = B; p.H = H; p.W = W; p.Cin = c8; p.Cout = Cout; p.taps = taps; p.bias = d.up(bias, Cout);
     p.A16 = d.up(xa.data(), xa.size()); p.lda16 = c8; p.Wt16 = d.up(wa.data(), wa.size());
-    p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES);
+    p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); p.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
     float* o = d.alloc<float>(M * Cout);
     p.out = o; p.ldo = Cout;
     if (!gemm16_can_fuse_gn(p, groups)) throw std::runtime_error("conv_gnstats: shape cannot fuse the statistics");
@@ -250,7 +250,7 @@ int ddpmir_op_conv_dual_bf16(const float* x1, int B, int H, int W, int C1, const
     p.B = B; p.H = H; p.W = W; p.Cin = c18; p.Cout = Cout; p.taps = taps; p.bias = d.up(bias, Cout);
     p.A16 = d.up(xa.data(), xa.size()); p.lda16 = c18; p.Wt16 = d.up(wa.data(), wa.size());
     p.A16b = d.up(xb.data(), xb.size()); p.lda16b = c28; p.Wt16b = d.up(wb.data(), wb.size()); p.Cinb = c28;
-    p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES);
+    p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); p.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
     float* o = d.alloc<float>(M * Cout);
     p.out = o; p.ldo = Cout;
     launch_gemm16(p, nullptr);
@@ -277,7 +277,7 @@ int ddpmir_op_qkv_attention_bf16(const float* x, int B, int N, int C, int heads,
     void* ws = d.alloc<unsigned char>(attention_bf16_workspace(B, N, C, heads));
     IGemm p;
     p.B = B; p.H = 1; p.W = N; p.Cin = C; p.Cout = 3 * C; p.taps = 1; p.bias = d.up(b_in, (size_t)3 * C);
-    p.A16 = a16; p.lda16 = C; p.Wt16 = d.up(w16.data(), w16.size()); p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES);
+    p.A16 = a16; p.lda16 = C; p.Wt16 = d.up(w16.data(), w16.size()); p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); p.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
     float* qkv = nullptr;
     if (fused) {
       const AttnPack16 t = attention_bf16_pack_targets(B, N, C, heads, ws);
