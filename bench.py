@@ -52,10 +52,7 @@ def cpu_baseline(size: int, quality: int, n_steps: int = 1):
         if quality < 20 and i % 5 == 0:
             x_t = O.phase_consistency(x_t, y, 0.7)
     dt = (time.perf_counter() - t0) / n_steps
-    try:    # cores this process may run on (the GPU box gives each job a CPU share, not the whole host)
-        threads = len(os.sched_getaffinity(0))
-    except AttributeError:
-        threads = os.cpu_count() or 1
+    threads = O.oracle_threads()    # the oracle's attention fans out over this many threads (BLAS single-threaded inside)
     return {"value": 1.0 / (dt * T_STEPS), "unit": "images/sec", "cores": int(threads), "kind": "port",
             "sample": f"numpy oracle, B=1 {size}x{size}, {n_steps} of {T_STEPS} timesteps, {dt:.2f} s/step"}
 
@@ -73,7 +70,11 @@ def main():
     ap.add_argument("--codec", choices=["host", "device"], default="device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full", action="store_true", help="time one complete T-step restoration instead of a slice")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:      # child process of the N=1 run: numpy oracle only, never touches the GPU
+        print(json.dumps(cpu_baseline(args.size, args.quality)), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -161,7 +162,18 @@ def main():
         if roof:
             line["roofline"] = roof
         if not args.no_cpu_baseline and env.world == 1:     # the CPU baseline is timed at N=1 only
-            line["cpu_baseline"] = cpu_baseline(R, q)
+            # in a child process: a failure of the host-side numpy / BLAS stack must not take the measured line with it
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(R),
+                                    "--quality", str(q)], capture_output=True, text=True, timeout=600)
+                out = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                line["cpu_baseline"] = json.loads(out[-1]) if (r.returncode == 0 and out) else \
+                    {"value": None, "unit": "images/sec", "cores": 0, "kind": "port",
+                     "sample": "cpu baseline process failed (rc %d): %s" % (r.returncode, r.stderr.strip()[-200:])}
+            except Exception as e:  # timeout etc.
+                line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port",
+                                        "sample": "cpu baseline not measured: %r" % (e,)}
         print(json.dumps(line), flush=True)
     D.barrier(env)
     if env.world > 1:

@@ -176,10 +176,9 @@ def mha(tokens, in_w, in_b, out_w, out_b, heads):
             from threadpoolctl import threadpool_limits
         except ImportError:
             threadpool_limits = None
-        try:
-            nthreads = max(1, len(os.sched_getaffinity(0)))
-        except AttributeError:
-            nthreads = max(1, os.cpu_count() or 1)
+        # at most 32 worker threads: OpenBLAS keeps a fixed table of per-caller buffers (128 in the numpy wheel) and aborts
+        # the process when more threads than that call into it -- seen with 256 threads on the MI355X host
+        nthreads = oracle_threads()
         with ThreadPoolExecutor(nthreads) as ex:
             if threadpool_limits is not None:
                 with threadpool_limits(limits=1):
@@ -188,6 +187,16 @@ def mha(tokens, in_w, in_b, out_w, out_b, heads):
                 list(ex.map(run, jobs))
     out = out.transpose(0, 2, 1, 3).reshape(b, n, c)
     return linear(out, out_w, out_b)
+
+
+def oracle_threads():
+    """Threads the oracle's attention uses (also what bench.py reports as `cpu_baseline.cores`)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(32, n))
 
 
 def blockwise_transform(x, mats):
