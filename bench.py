@@ -141,7 +141,9 @@ def main():
                 # (FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE/2 [the model writes bf16]) KiB on a B=4 launch, scaled by B/4;
                 # not collected live
                 "traffic": (2 * 271936.5 + 65536 / 2) * 1024 * (B / 4.0) if (args.dtype == "bf16" and R == 256) else None,
-                "valu_bound_note": "bound by v_exp_f32 issue (32 FLOP per exp at head_dim 16): VALU pipe ~80% busy, MFMA pipe ~39%",
+                "valu_bound_note": ("bound by v_exp_f32 issue (32 FLOP per exp at head_dim 16): VALU pipe ~80% busy, MFMA pipe ~39%"
+                                    if args.dtype == "bf16" else
+                                    "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); the 32-row PV tile is half empty at head_dim 16"),
                 "avg_launch_ms": a_ms / a_n, "launches": a_n, "forward_ms": (f_ms / f_n) if f_n else None}
 
     if env.rank == 0:
