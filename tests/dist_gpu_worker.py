@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_dist.py: one rank of a 2-rank restoration job whose ranks share GPU 0 (gloo collectives;
+"""Worker of tests/test_gpu_bench_and_dist.py: one rank of a 2-rank restoration job whose ranks share GPU 0 (gloo collectives;
 RCCL needs one GPU per rank).  Rank 0 also restores the whole batch alone and checks the gathered shards against it."""
 import os
 import sys
