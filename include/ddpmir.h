@@ -40,7 +40,7 @@ typedef struct ddpmir_ctx ddpmir_ctx;
 
 typedef struct ddpmir_config {
   int arch;            /* DDPMIR_ARCH_* */
-  int dtype;           /* DDPMIR_F32 (parity mode) | DDPMIR_BF16 (activations/weights bf16 on the matrix cores) */
+  int dtype;           /* DDPMIR_F32 (parity mode) | DDPMIR_BF16 (bf16 matrix-core operands, fp32 accumulation and storage) */
   int attn_min_level;  /* 0 = self-attention in all 13 blocks (the reference, webp_inference.py:317-321);
                           5 = bottleneck blocks only (the variant BASELINE.json's configs describe) */
   int device;          /* HIP device ordinal */
