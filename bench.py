@@ -79,10 +79,9 @@ def main():
     import numpy as np
     import torch
     from ddpm_image_restoration_amd import dist as D
-    from ddpm_image_restoration_amd import spec, synth
+    from ddpm_image_restoration_amd import codec, spec, synth
     from ddpm_image_restoration_amd.model import JPEGDiffusionModel
     from ddpm_image_restoration_amd.sampler import DDRMJPEGSampler
-    from oracle import ddpm_oracle as O   # checker / cpu_baseline leg only
 
     env = D.init_from_env()
     if env.world != args.gpus:
@@ -100,7 +99,7 @@ def main():
     n_total = B * env.world
     lo, hi = D.shard_range(n_total, env.rank, env.world)
     x0 = synth.synth_images(n_total, R, seed=123)[lo:hi]
-    y = torch.from_numpy(O.compress(x0, q, "jpeg")).to(dev)
+    y = codec.jpeg_compress(torch.from_numpy(x0), q).to(dev)     # y = JPEG(x0, q): the product's own host codec
     dev_codec = args.codec == "device"
 
     K, W = max(1, args.steps), max(0, args.warmup)
