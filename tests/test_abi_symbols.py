@@ -64,3 +64,19 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle|oracle[./]ddpm_oracle|import_module\(.oracle", txt, flags=re.M), \
                     f"{f} reaches into oracle/"
+
+
+def test_bench_touches_the_oracle_only_in_its_cpu_baseline_leg():
+    """bench.py may use oracle/ for the `cpu_baseline` object and nothing else: every import of it sits inside
+    cpu_baseline(), which the N=1 run executes in a child process."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    offenders = []
+    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+        for node in ast.iter_child_nodes(fn) if isinstance(fn, ast.Module) else ast.walk(fn):
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                names = [a.name for a in node.names] + [getattr(node, "module", "") or ""]
+                if any(n.split(".")[0] == "oracle" for n in names):
+                    if not (isinstance(fn, ast.FunctionDef) and fn.name == "cpu_baseline"):
+                        offenders.append((getattr(fn, "name", "<module>"), node.lineno))
+    assert not offenders, offenders
