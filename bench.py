@@ -136,10 +136,10 @@ def main():
         achieved = a_fl / (a_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "flash attention, N=%d tokens, head_dim 16 (down1/up5)" % (R * R),
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                # HBM bytes per launch from the committed PMC passes (profiles/r01_attn_bf16_pmc_{fetch,write}.csv:
-                # (FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE/2 [the model writes bf16]) KiB on a B=4 launch, scaled by B/4;
-                # not collected live
-                "traffic": (2 * 271936.5 + 65536 / 2) * 1024 * (B / 4.0) if (args.dtype == "bf16" and R == 256) else None,
+                # HBM-side bytes per launch from the committed PMC passes over this very command (tools/pmc_traffic.sh ->
+                # profiles/r01_bench_bf16_pmc_{fetch,write}.csv, level-0 launches at B=16: FETCH_SIZE 1 147 940 KiB x2 [gfx950
+                # correction] + WRITE_SIZE 131 072 KiB), scaled by B/16; rocprofv3 counters cannot be read from inside the run
+                "traffic": (2 * 1147939.6 + 131072.0) * 1024 * (B / 16.0) if (args.dtype == "bf16" and R == 256) else None,
                 "valu_bound_note": ("bound by v_exp_f32 issue (32 FLOP per exp at head_dim 16): VALU pipe ~80% busy, MFMA pipe ~39%"
                                     if args.dtype == "bf16" else
                                     "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); the 32-row PV tile is half empty at head_dim 16"),
