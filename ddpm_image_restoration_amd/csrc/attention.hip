@@ -11,6 +11,8 @@
 //   32x32x2 MFMA takes from lane half h at step s -- no shuffle, no LDS round trip for P.
 // small_f32: one wave per query row, scores in LDS; used for tiny maps (N < 64) and head_dim > 128
 // (bottleneck blocks, N <= 1024).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace ddpmir {
@@ -138,6 +140,109 @@ __global__ __launch_bounds__(256) void flash_f32(const float* __restrict__ qkv, 
   }
 }
 
+// head_dim 16 (the full-resolution levels, 95 % of the exact-fp32 FLOPs): v_mfma_f32_16x16x4_f32 tiles.  The 32x32x2
+// tile above spends a 32-row PV product on 16 useful rows; here S^T (16 keys x 16 queries) and O^T (16 dims x 16 queries)
+// are both exact fits: 8 MFMAs of 32 cycles per 256 scores instead of 12 x 64 per 1024 -> 1024 vs 1536 cycles per 1024.
+// Layouts (lane l: g = l / 16, n = l % 16):  A[m = n][k = g], B[k = g][n], C/D[m = 4g + r][n], r = 0..3.
+//   S^T = K Q^T:  A = K[key n][dim 4j + g] (LDS, dims permuted so the four j are one float4), B = Q[query n][dim 4j + g]
+//   lane (g, n) then owns keys 4g..4g+3 of query n; used as B of the PV product step j it supplies key 4g + j, so the
+//   A operand of step j is V[key 4g + j][dim n] (LDS holds V as [key group g][dim][j]: one float4 per lane and tile).
+// One wave = 32 queries (two 16-query halves sharing every K/V fragment), exact online softmax per 16-key tile.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void flash_f32_d16(const float* __restrict__ qkv, float* __restrict__ out, int ldo, int N,
+                                                     int C, float qscale) {
+  constexpr int D = 16, KS = 64;                       // keys per LDS stage (4 tiles of 16)
+  __shared__ __attribute__((aligned(16))) float Ks[KS * D];       // [key][g][j]  = K[key][4j + g]
+  __shared__ __attribute__((aligned(16))) float Vs[KS * D];       // [key / 4][dim][key % 4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int ld = 3 * C;
+  const float* base = qkv + (size_t)b * N * ld + head * D;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  float qf[2][4];                                      // B operand of S^T: Q[query 16h + n][dim 4j + g], pre-scaled
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int qr = min(q0 + 16 * h + n, N - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qf[h][j] = base[(size_t)qr * ld + 4 * j + g] * qscale;
+  }
+  f32x4 o[2];
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { o[h] = f32x4{0.f, 0.f, 0.f, 0.f}; m_run[h] = -INFINITY; l_run[h] = 0.f; }
+
+  const int nstages = (N + KS - 1) / KS;
+  for (int st = 0; st < nstages; ++st) {
+    __syncthreads();                                   // previous stage fully consumed
+    for (int idx = tid; idx < KS * 4; idx += 256) {    // one float4 of K and of V per (key, 4-dim chunk)
+      const int row = idx >> 2, c4 = idx & 3, key = st * KS + row;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (key < N) {
+        const float* rp = base + (size_t)key * ld + 4 * c4;
+        kv = *reinterpret_cast<const float4*>(rp + C);
+        vv = *reinterpret_cast<const float4*>(rp + 2 * C);
+      }
+      // K[key][4 c4 + e] -> Ks[key][g = e][j = c4];  V[key][4 c4 + e] -> Vs[key / 4][dim = 4 c4 + e][key % 4]
+      Ks[row * D + 0 * 4 + c4] = kv.x; Ks[row * D + 1 * 4 + c4] = kv.y; Ks[row * D + 2 * 4 + c4] = kv.z; Ks[row * D + 3 * 4 + c4] = kv.w;
+      float* vp = Vs + (row >> 2) * (D * 4) + (row & 3);
+      vp[(4 * c4 + 0) * 4] = vv.x; vp[(4 * c4 + 1) * 4] = vv.y; vp[(4 * c4 + 2) * 4] = vv.z; vp[(4 * c4 + 3) * 4] = vv.w;
+    }
+    __syncthreads();
+    const int tiles = min(KS / 16, (N - st * KS + 15) / 16);
+    for (int t = 0; t < tiles; ++t) {
+      const float4 ka = *reinterpret_cast<const float4*>(&Ks[(t * 16 + n) * D + g * 4]);          // K[key n][4j + g], j = 0..3
+      const float4 va = *reinterpret_cast<const float4*>(&Vs[((t * 4 + g) * D + n) * 4]);         // V[key 4g + j][dim n]
+      const int kbase = st * KS + t * 16 + 4 * g;                                                  // this lane's first key
+      const bool ragged = kbase + 3 >= N;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qf[h][0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qf[h][1], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.z, qf[h][2], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.w, qf[h][3], s, 0, 0, 0);
+        if (ragged) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kbase + r >= N) s[r] = -INFINITY;
+        }
+        float tmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run[h], tmax);
+        if (__any(m_new > m_run[h])) {                 // wave-uniform: rescale only when some row's maximum moved
+          const float alpha = __builtin_amdgcn_exp2f(m_run[h] - m_new);   // raw v_exp_f32; exp2(-inf) = 0 on the first tile
+          o[h] *= alpha;
+          l_run[h] *= alpha;
+          m_run[h] = m_new;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - m_run[h]);   // arguments <= 0: no range fix-up needed
+        l_run[h] += (s[0] + s[1]) + (s[2] + s[3]);
+        o[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, s[0], o[h], 0, 0, 0);
+        o[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, s[1], o[h], 0, 0, 0);
+        o[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, s[2], o[h], 0, 0, 0);
+        o[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, s[3], o[h], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float l = l_run[h];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const int qr = q0 + 16 * h + n;
+    if (qr < N) {
+      const float inv = 1.0f / l;
+      *reinterpret_cast<float4*>(out + ((size_t)b * N + qr) * ldo + head * D + 4 * g) =
+          make_float4(o[h][0] * inv, o[h][1] * inv, o[h][2] * inv, o[h][3] * inv);
+    }
+  }
+}
+
 // one wave per query row; scores of the row live in LDS (N <= SMALL_MAXN)
 constexpr int SMALL_MAXN = 1024;
 
@@ -198,7 +303,10 @@ void launch_attention(const float* qkv, float* out, int ldo, int B, int N, int C
   dim3 grid(cdiv(N, 128), heads, B), block(256);
   switch (D) {
     case 8: hipLaunchKernelGGL(flash_f32<8>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;
-    case 16: hipLaunchKernelGGL(flash_f32<16>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;
+    case 16:
+      if (getenv("DDPMIR_ATTN_F32_OLD")) { hipLaunchKernelGGL(flash_f32<16>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break; }
+      hipLaunchKernelGGL(flash_f32_d16, grid, block, 0, stream, qkv, out, ldo, N, C, qscale);
+      break;
     case 32: hipLaunchKernelGGL(flash_f32<32>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;
     case 64: hipLaunchKernelGGL(flash_f32<64>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;
     case 128: hipLaunchKernelGGL(flash_f32<128>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;
