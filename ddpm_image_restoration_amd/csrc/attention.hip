@@ -148,13 +148,16 @@ __global__ __launch_bounds__(256) void flash_f32(const float* __restrict__ qkv, 
 //   lane (g, n) then owns keys 4g..4g+3 of query n; used as B of the PV product step j it supplies key 4g + j, so the
 //   A operand of step j is V[key 4g + j][dim n] (LDS holds V as [key group g][dim][j]: one float4 per lane and tile).
 // One wave = 32 queries (two 16-query halves sharing every K/V fragment), exact online softmax per 16-key tile.
+// head_dim 8 (the AVIF family's level 0, 8 heads) uses the same tiles with two k-steps and half of the O^T rows.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void flash_f32_d16(const float* __restrict__ qkv, float* __restrict__ out, int ldo, int N,
+template <int D>   // D = 8 (AVIF level 0: half of the 16 output rows stay empty) or 16 (exact fit)
+__global__ __launch_bounds__(256) void flash_f32_t16(const float* __restrict__ qkv, float* __restrict__ out, int ldo, int N,
                                                      int C, float qscale) {
-  constexpr int D = 16, KS = 64;                       // keys per LDS stage (4 tiles of 16)
+  constexpr int KS = 64;                               // keys per LDS stage (4 tiles of 16)
+  constexpr int NJ = D / 4;                            // k-steps of the S^T product
   __shared__ __attribute__((aligned(16))) float Ks[KS * D];       // [key][g][j]  = K[key][4j + g]
-  __shared__ __attribute__((aligned(16))) float Vs[KS * D];       // [key / 4][dim][key % 4]
+  __shared__ __attribute__((aligned(16))) float Vs[KS * 16];      // [key / 4][dim 0..15][key % 4] (dims >= D stay zero)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int head = blockIdx.y, b = blockIdx.z;
@@ -162,13 +165,15 @@ __global__ __launch_bounds__(256) void flash_f32_d16(const float* __restrict__ q
   const float* base = qkv + (size_t)b * N * ld + head * D;
   const int q0 = blockIdx.x * 128 + wave * 32;
 
-  float qf[2][4];                                      // B operand of S^T: Q[query 16h + n][dim 4j + g], pre-scaled
+  float qf[2][NJ];                                     // B operand of S^T: Q[query 16h + n][dim 4j + g], pre-scaled
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int qr = min(q0 + 16 * h + n, N - 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) qf[h][j] = base[(size_t)qr * ld + 4 * j + g] * qscale;
+    for (int j = 0; j < NJ; ++j) qf[h][j] = base[(size_t)qr * ld + 4 * j + g] * qscale;
   }
+  if (D < 16)
+    for (int i = tid; i < KS * 16; i += 256) Vs[i] = 0.f;
   f32x4 o[2];
   float m_run[2], l_run[2];
 #pragma unroll
@@ -176,9 +181,9 @@ __global__ __launch_bounds__(256) void flash_f32_d16(const float* __restrict__ q
 
   const int nstages = (N + KS - 1) / KS;
   for (int st = 0; st < nstages; ++st) {
-    __syncthreads();                                   // previous stage fully consumed
-    for (int idx = tid; idx < KS * 4; idx += 256) {    // one float4 of K and of V per (key, 4-dim chunk)
-      const int row = idx >> 2, c4 = idx & 3, key = st * KS + row;
+    __syncthreads();                                   // previous stage fully consumed (and the zero fill ordered)
+    for (int idx = tid; idx < KS * NJ; idx += 256) {   // one float4 of K and of V per (key, 4-dim chunk)
+      const int row = idx / NJ, c4 = idx - row * NJ, key = st * KS + row;
       float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
       if (key < N) {
         const float* rp = base + (size_t)key * ld + 4 * c4;
@@ -186,24 +191,24 @@ __global__ __launch_bounds__(256) void flash_f32_d16(const float* __restrict__ q
         vv = *reinterpret_cast<const float4*>(rp + 2 * C);
       }
       // K[key][4 c4 + e] -> Ks[key][g = e][j = c4];  V[key][4 c4 + e] -> Vs[key / 4][dim = 4 c4 + e][key % 4]
-      Ks[row * D + 0 * 4 + c4] = kv.x; Ks[row * D + 1 * 4 + c4] = kv.y; Ks[row * D + 2 * 4 + c4] = kv.z; Ks[row * D + 3 * 4 + c4] = kv.w;
-      float* vp = Vs + (row >> 2) * (D * 4) + (row & 3);
+      Ks[row * D + 0 * NJ + c4] = kv.x; Ks[row * D + 1 * NJ + c4] = kv.y; Ks[row * D + 2 * NJ + c4] = kv.z; Ks[row * D + 3 * NJ + c4] = kv.w;
+      float* vp = Vs + (row >> 2) * (16 * 4) + (row & 3);
       vp[(4 * c4 + 0) * 4] = vv.x; vp[(4 * c4 + 1) * 4] = vv.y; vp[(4 * c4 + 2) * 4] = vv.z; vp[(4 * c4 + 3) * 4] = vv.w;
     }
     __syncthreads();
     const int tiles = min(KS / 16, (N - st * KS + 15) / 16);
     for (int t = 0; t < tiles; ++t) {
-      const float4 ka = *reinterpret_cast<const float4*>(&Ks[(t * 16 + n) * D + g * 4]);          // K[key n][4j + g], j = 0..3
-      const float4 va = *reinterpret_cast<const float4*>(&Vs[((t * 4 + g) * D + n) * 4]);         // V[key 4g + j][dim n]
+      float ka[NJ];                                                                                // K[key n][4j + g], j < NJ
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) ka[j] = Ks[(t * 16 + n) * D + g * NJ + j];
+      const float4 va = *reinterpret_cast<const float4*>(&Vs[((t * 4 + g) * 16 + n) * 4]);        // V[key 4g + j][dim n]
       const int kbase = st * KS + t * 16 + 4 * g;                                                  // this lane's first key
       const bool ragged = kbase + 3 >= N;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qf[h][0], s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qf[h][1], s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.z, qf[h][2], s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.w, qf[h][3], s, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j], qf[h][j], s, 0, 0, 0);
         if (ragged) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256) void flash_f32_d16(const float* __restrict__ q
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
     const int qr = q0 + 16 * h + n;
-    if (qr < N) {
+    if (qr < N && 4 * g < D) {                         // lane (g, n) holds dims 4g..4g+3 of query n
       const float inv = 1.0f / l;
       *reinterpret_cast<float4*>(out + ((size_t)b * N + qr) * ldo + head * D + 4 * g) =
           make_float4(o[h][0] * inv, o[h][1] * inv, o[h][2] * inv, o[h][3] * inv);
@@ -302,10 +307,13 @@ void launch_attention(const float* qkv, float* out, int ldo, int B, int N, int C
   const float qscale = scale * 1.44269504088896340736f;
   dim3 grid(cdiv(N, 128), heads, B), block(256);
   switch (D) {
-    case 8: hipLaunchKernelGGL(flash_f32<8>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;
+    case 8:
+      if (getenv("DDPMIR_ATTN_F32_OLD")) { hipLaunchKernelGGL(flash_f32<8>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break; }
+      hipLaunchKernelGGL(flash_f32_t16<8>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale);
+      break;
     case 16:
       if (getenv("DDPMIR_ATTN_F32_OLD")) { hipLaunchKernelGGL(flash_f32<16>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break; }
-      hipLaunchKernelGGL(flash_f32_d16, grid, block, 0, stream, qkv, out, ldo, N, C, qscale);
+      hipLaunchKernelGGL(flash_f32_t16<16>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale);
       break;
     case 32: hipLaunchKernelGGL(flash_f32<32>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;
     case 64: hipLaunchKernelGGL(flash_f32<64>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;
