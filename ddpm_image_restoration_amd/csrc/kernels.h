@@ -118,6 +118,9 @@ void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B
                             void* low16 = nullptr, void* high16 = nullptr, int low = 0);
 
 // out = a * b * c * d (+ base)   elementwise over [M][C] with per-tensor strides; null pointers are skipped
+// out = base + xt * (0.25 * sum of the four bilinearly upsampled S x S gate maps, S = 1,2,4,8, stored back to back) * col * edge
+void launch_avif_combine(const float* base, const float* xt, const float* gates, const float* col, const float* edge,
+                         float* out, int B, int H, int W, int C, hipStream_t s);
 void launch_mul4_add(const float* base, int ldb, const float* a, int lda, const float* b, int ldb2, const float* c,
                      int ldc, const float* d, int ldd, float* out, int ldo, int64_t M, int C, hipStream_t s);
 

@@ -319,7 +319,7 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
     p.xt = a.take<float>(mc); p.avg = a.take<float>(mc); p.col = a.take<float>(mc); p.edge = a.take<float>(mc);
     p.pool = a.take<float>((size_t)B * 64 * 1024); p.pg1 = a.take<float>((size_t)B * 64 * 256);
     p.pool8 = a.take<float>((size_t)B * 64 * 1024);
-    p.pg2 = a.take<float>((size_t)B * 64 * 1024);
+    p.pg2 = a.take<float>((size_t)B * 85 * 1024);   // the four pooled gate maps (1 + 4 + 16 + 64 positions) back to back
   }
   if (cfg.dtype == DDPMIR_BF16) {
     size_t ws = 0;
@@ -506,11 +506,11 @@ void Context::avif_transform(const AvifTransformW& at, const float* x, int ldx, 
 void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
   Plan& p = plan_;
   const int B = fb_, C = bw.cout;
-  const int64_t M = (int64_t)B * H * W;
   avif_transform(bw.at, p.hB, C, C, H, W, p.xd, p.hid, p.xt, C, nullptr, nullptr, 0, s);
   const int scales[4] = {1, 2, 4, 8};
   const bool one_pass = pool8_supported(H, W, C);   // all four scales from one read of x
   if (one_pass) launch_pool8_sums(p.hB, C, p.pool8, B, H, W, C, s);
+  size_t goff = 0;
   for (int i = 0; i < 4; ++i) {
     const int S = scales[i];
     if (one_pass) launch_pool_from8(p.pool8, p.pool, C, B, H, W, C, S, s);
@@ -518,11 +518,10 @@ void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
     IGemm g; g.B = B; g.H = S; g.W = S;
     IGemm a = g; a.A = p.pool; a.lda = C; a.epi_act = ACT_RELU; a.out = p.pg1; a.ldo = C / 4;
     conv(bw.ms1[i], a, s);
-    IGemm b = g; b.A = p.pg1; b.lda = C / 4; b.epi_act = ACT_SIGMOID; b.out = p.pg2; b.ldo = C;
+    // the gate maps stay at S x S; F.interpolate(size=x.shape[-2:]) + the average happen inside avif_combine_k
+    IGemm b = g; b.A = p.pg1; b.lda = C / 4; b.epi_act = ACT_SIGMOID; b.out = p.pg2 + goff; b.ldo = C;
     conv(bw.ms3[i], b, s);
-    // F.interpolate(size=x.shape[-2:]) -> coordinate scale in/out; identical sizes reduce to a copy
-    launch_bilinear(p.pg2, C, p.avg, C, B, S, S, H, W, C, (float)S / (float)H, (float)S / (float)W, i > 0 ? 1 : 0,
-                    i == 3 ? 0.25f : 1.0f, s);
+    goff += (size_t)B * S * S * C;
   }
   IGemm g; g.B = B; g.H = H; g.W = W;
   if (use_gemm16()) {   // colour + edge gates on the bf16 copy of x (plan_.hB16, refreshed by out_proj)
@@ -534,7 +533,7 @@ void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
     conv16(bw.ep0, e0, s);
     IGemm e2 = g; e2.A16 = p.hid16; e2.lda16 = C / 2; e2.epi_act = ACT_SIGMOID; e2.rowscale = p.boost2; e2.out = p.edge; e2.ldo = C;
     conv16(bw.ep2, e2, s);
-    launch_mul4_add(p.hB, C, p.xt, C, p.avg, C, p.col, C, p.edge, C, p.S, C, M, C, s);
+    launch_avif_combine(p.hB, p.xt, p.pg2, p.col, p.edge, p.S, B, H, W, C, s);
     return;
   }
   IGemm c0 = g; c0.A = p.hB; c0.lda = C; c0.epi_act = ACT_RELU; c0.out = p.hid; c0.ldo = C;
@@ -545,7 +544,7 @@ void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
   conv(bw.ep0, e0, s);
   IGemm e2 = g; e2.A = p.hid; e2.lda = C / 2; e2.epi_act = ACT_SIGMOID; e2.rowscale = p.boost2; e2.out = p.edge; e2.ldo = C;
   conv(bw.ep2, e2, s);
-  launch_mul4_add(p.hB, C, p.xt, C, p.avg, C, p.col, C, p.edge, C, p.S, C, M, C, s);
+  launch_avif_combine(p.hB, p.xt, p.pg2, p.col, p.edge, p.S, B, H, W, C, s);
 }
 
 void Context::conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override) {

@@ -353,6 +353,52 @@ __global__ void mul4_add_k(const float* base, int ldb, const float* a, int lda, 
   }
 }
 
+// AVIF frequency block tail (avif_inference.py:227-256): out = base + xt * avg * col * edge, where
+// avg = 0.25 * (up(g1) + up(g2) + up(g4) + up(g8)) and up() is F.interpolate(size=(H, W), bilinear, align_corners=False)
+// of the S x S pooled gates.  The four tiny gate maps are interpolated on the fly (same summation order as the
+// accumulate-then-scale passes this replaces), so the full-resolution `avg` tensor is never written or re-read.
+__global__ void avif_combine_k(const float* __restrict__ base, const float* __restrict__ xt, const float* __restrict__ gates,
+                               const float* __restrict__ col, const float* __restrict__ edge, float* __restrict__ out, int B,
+                               int H, int W, int C4) {
+  const int64_t total = (int64_t)B * H * W * C4;
+  const int C = C4 * 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = i % C4;
+    int64_t m = i / C4;
+    int64_t q = m;
+    const int xo = q % W; q /= W;
+    const int yo = q % H; const int b = q / H;
+    float4 avg = make_float4(0.f, 0.f, 0.f, 0.f);
+    size_t goff = 0;                                   // gate maps are stored back to back: [B][S][S][C] for S = 1, 2, 4, 8
+#pragma unroll
+    for (int si = 0; si < 4; ++si) {
+      const int S = 1 << si;
+      int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+      lin_coord(yo, S, (float)S / (float)H, y0, y1, wy0, wy1);
+      lin_coord(xo, S, (float)S / (float)W, x0, x1, wx0, wx1);
+      const float* ib = gates + goff + (size_t)b * S * S * C + 4 * c4;
+      const float4 v00 = *reinterpret_cast<const float4*>(ib + ((size_t)y0 * S + x0) * C);
+      const float4 v01 = *reinterpret_cast<const float4*>(ib + ((size_t)y0 * S + x1) * C);
+      const float4 v10 = *reinterpret_cast<const float4*>(ib + ((size_t)y1 * S + x0) * C);
+      const float4 v11 = *reinterpret_cast<const float4*>(ib + ((size_t)y1 * S + x1) * C);
+      avg.x += wy0 * (wx0 * v00.x + wx1 * v01.x) + wy1 * (wx0 * v10.x + wx1 * v11.x);
+      avg.y += wy0 * (wx0 * v00.y + wx1 * v01.y) + wy1 * (wx0 * v10.y + wx1 * v11.y);
+      avg.z += wy0 * (wx0 * v00.z + wx1 * v01.z) + wy1 * (wx0 * v10.z + wx1 * v11.z);
+      avg.w += wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
+      goff += (size_t)B * S * S * C;
+    }
+    float4 v = *reinterpret_cast<const float4*>(xt + m * C + 4 * c4);
+    const float4 cw = *reinterpret_cast<const float4*>(col + m * C + 4 * c4);
+    const float4 ew = *reinterpret_cast<const float4*>(edge + m * C + 4 * c4);
+    const float4 bw = *reinterpret_cast<const float4*>(base + m * C + 4 * c4);
+    v.x = v.x * (avg.x * 0.25f) * cw.x * ew.x + bw.x;
+    v.y = v.y * (avg.y * 0.25f) * cw.y * ew.y + bw.y;
+    v.z = v.z * (avg.z * 0.25f) * cw.z * ew.z + bw.z;
+    v.w = v.w * (avg.w * 0.25f) * cw.w * ew.w + bw.w;
+    *reinterpret_cast<float4*>(out + m * C + 4 * c4) = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------- time embedding
 // one workgroup per sample: sinusoid -> Linear(256,1024) -> SiLU -> Linear(1024,256)
 __global__ __launch_bounds__(256) void time_embed_k(const float* __restrict__ t, TimeEmbedW w,
@@ -534,6 +580,13 @@ void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B
                        C, mats, per_channel, mix_in, mix_t, l16, h16, low);
   else
     throw std::runtime_error("block transform: block size must be 4 or 8");
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_avif_combine(const float* base, const float* xt, const float* gates, const float* col, const float* edge,
+                         float* out, int B, int H, int W, int C, hipStream_t s) {
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  hipLaunchKernelGGL(avif_combine_k, dim3(grid_for(total)), dim3(256), 0, s, base, xt, gates, col, edge, out, B, H, W, C / 4);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
