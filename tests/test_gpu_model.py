@@ -388,3 +388,31 @@ def test_forward_128_against_reference(name, arch, models):
     e16 = np.abs(models(arch, dtype="bf16")(x, tt(g["t"]), tt(g["cl"])).cpu().numpy() - g["y"])
     assert e16.max() < 2e-2 and e16.mean() < 2e-3, (e16.max(), e16.mean())
     print(f"{name} 128x128 vs reference: fp32 max {err.max():.2e}; bf16 max {e16.max():.2e} mean {e16.mean():.2e}")
+
+
+def test_create_destroy_does_not_leak_device_memory(synth_state):
+    """Contexts own their weights and workspace: building, running and dropping a model repeatedly leaves the free device
+    memory where it was (ddpmir_destroy frees the blob, both plans' arenas, pinned buffers, streams and events)."""
+    import gc
+    import torch
+    from ddpm_image_restoration_amd.model import WebPDiffusionModel
+    from ddpm_image_restoration_amd.sampler import DDRMWebPSampler
+    sd = synth_state(spec.ARCH_WEBP)
+    x = tt(synth.synth_images(2, 64, seed=3))
+    t = torch.full((2,), 0.5, device="cuda")
+
+    def cycle():
+        m = WebPDiffusionModel(device=torch.device("cuda", 0), dtype="bf16")
+        m.load_state_dict(sd)
+        m(x, t, t)
+        DDRMWebPSampler(m).sample(x, 50, steps=2, seed=1)
+        del m
+        gc.collect()
+        torch.cuda.synchronize()
+
+    cycle()                                             # first cycle: lazy runtime allocations (code objects, pools)
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        cycle()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)     # nothing the size of a weight blob (450 MB+) or an arena is left behind
