@@ -416,3 +416,21 @@ def test_create_destroy_does_not_leak_device_memory(synth_state):
         cycle()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, (free0, free1)     # nothing the size of a weight blob (450 MB+) or an arena is left behind
+
+
+@pytest.mark.parametrize("H,W", [(160, 160), (32, 224), (96, 32)])
+def test_forward_sizes_with_ragged_levels(H, W, models):
+    """Sizes whose deep levels are not multiples of the kernel tiles (160 -> 5x5 maps, 25 tokens; 224 x 32 -> 7 x 1): the
+    fused epilogues fall back where their alignment rules do not hold; bf16 mode must still agree with fp32 mode, and
+    fp32 mode with the oracle."""
+    import torch
+    x = synth.synth_images(1, max(H, W), seed=70)[:, :, :H, :W].copy()
+    t = np.array([0.45], np.float32)
+    y32 = models(spec.ARCH_JPEG)(tt(x), tt(t), tt(t))
+    y16 = models(spec.ARCH_JPEG, dtype="bf16")(tt(x), tt(t), tt(t))
+    e = (y16 - y32).abs()
+    assert torch.isfinite(y16).all() and float(e.max()) < 2e-2 and float(e.mean()) < 2e-3, (float(e.max()), float(e.mean()))
+    if H * W <= 32 * 224:                                # the oracle takes seconds at these sizes
+        from ddpm_image_restoration_amd import synth as S
+        ref = O.Model(spec.ARCH_JPEG, S.synth_state_dict(spec.ARCH_JPEG, 0)).forward(x, t, t)
+        assert np.abs(y32.cpu().numpy() - ref).max() < TOL
