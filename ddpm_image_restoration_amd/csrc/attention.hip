@@ -26,7 +26,7 @@ constexpr int KT = 32;   // keys per tile
 template <int D>
 __global__ __launch_bounds__(256) void flash_f32(const float* __restrict__ qkv, float* __restrict__ out, int ldo,
                                                  int N, int C, float qscale) {
-  constexpr int DP = D + 4;                  // padded K row (conflict-free b128 reads)
+  constexpr int DP = D >= 256 ? D : D + 4;   // padded K row (conflict-free b128 reads); 256: 64 KiB of static LDS is the limit
   constexpr int DV = D < 32 ? 32 : D;        // V row width (>= one 32-wide dd tile)
   constexpr int DT = DV / 32;
   constexpr int QC = D / 8;                  // 8-wide d chunks
@@ -296,7 +296,7 @@ void launch_attention(const float* qkv, float* out, int ldo, int B, int N, int C
   const int D = C / heads;
   if (D * heads != C || (D % 8) != 0) throw std::runtime_error("attention: head_dim must be a multiple of 8");
   const float scale = 1.0f / sqrtf((float)D);
-  const bool flash_ok = (D == 8 || D == 16 || D == 32 || D == 64 || D == 128) && N >= 64;
+  const bool flash_ok = (D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256) && N >= 64;
   if (!flash_ok) {
     if (N > SMALL_MAXN) throw std::runtime_error("attention: head_dim > 128 needs N <= 1024 tokens");
     dim3 grid(cdiv(N, 4), heads, B);
@@ -318,6 +318,9 @@ void launch_attention(const float* qkv, float* out, int ldo, int B, int N, int C
     case 32: hipLaunchKernelGGL(flash_f32<32>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;
     case 64: hipLaunchKernelGGL(flash_f32<64>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;
     case 128: hipLaunchKernelGGL(flash_f32<128>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;
+    // bottleneck blocks (C = 1024, 4 heads): 64..1024 tokens.  ~300 VGPRs (one wave per SIMD) but two orders of magnitude
+    // fewer instructions than the scalar small_f32 path it replaces (1.1 ms -> see DESIGN 4 at 256 tokens)
+    case 256: hipLaunchKernelGGL(flash_f32<256>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;
   }
   DDPMIR_HIP_CHECK(hipGetLastError());
 }

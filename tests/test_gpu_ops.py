@@ -192,7 +192,7 @@ def test_frequency_gates(ops, H, W, bs, low):
 
 @pytest.mark.parametrize("N,C,heads", [(256, 64, 4), (1024, 64, 4), (256, 128, 4), (64, 256, 4), (64, 512, 4),
                                        (16, 512, 4), (4, 1024, 4), (1, 1024, 4), (96, 64, 8), (200, 128, 8),
-                                       (64, 1024, 8), (4, 1024, 8)])
+                                       (64, 1024, 8), (4, 1024, 8), (64, 1024, 4), (256, 1024, 4), (100, 1024, 4)])
 def test_attention(ops, N, C, heads):
     B = 2
     qkv = rnd(B, N, 3 * C, seed=23, scale=1.5)
