@@ -19,9 +19,10 @@ DEFAULT_QUALITIES = {spec.ARCH_WEBP: [0, 5, 10, 30, 50, 70, 90],      # webp_inf
 
 
 def steps_for_quality(arch: int, quality: int) -> int:
-    """init_t = clamp(int(100 - q), lo, hi)   (webp_inference.py:678-679, avif_inference.py:534-535)."""
+    """init_t = int((100 - q) / 100 * 100), clamped to [lo, hi]   (webp_inference.py:678-679, avif_inference.py:534-535).
+    The reference forms the product in floating point, which gives one step fewer than 100 - q at q = 42, 43, 71."""
     k = spec.CONSTS[arch]
-    return max(k.steps_lo, min(k.steps_hi, int(100 - quality)))
+    return max(k.steps_lo, min(k.steps_hi, int((100 - quality) / 100 * 100)))
 
 
 def psnr(a, b):
@@ -72,22 +73,26 @@ def ssim(a, b, win_size=11, sigma=1.5, k1=0.01, k2=0.03):
 def test_restoration(model, sampler, images, quality_levels=None, output_dir=None, seed=0, env=None):
     """images: iterable of [B,3,H,W] tensors in [-1,1].  Returns {quality: averaged metrics} like the reference's
     avg_results and writes metrics_summary.json when output_dir is given.  With a DistEnv the image list is
-    sharded across ranks and the sums are all-reduced."""
+    sharded across ranks and the sums are all-reduced.  The device noise of every image is keyed by (seed, GLOBAL image
+    index), so restored images and metrics do not depend on the number of ranks."""
     import torch
     from . import dist as D
     arch = model.ARCH
     qs = quality_levels or DEFAULT_QUALITIES[arch]
     batches = list(images)
+    first = [0]                                   # global index of the first image of every batch
+    for b in batches:
+        first.append(first[-1] + int(b.shape[0]))
     if env is not None and env.world > 1:
         lo, hi = D.shard_range(len(batches), env.rank, env.world)
-        batches = batches[lo:hi]
+        batches, first = batches[lo:hi], first[lo:hi]
     results = {}
     for q in qs:
         acc = [0.0] * 7
         for bi, x0 in enumerate(batches):
             x0 = x0.to(model.device)
             y = COMPRESS[arch](x0, q)
-            restored = sampler.sample(y, q, steps=steps_for_quality(arch, q), seed=seed + bi)
+            restored = sampler.sample(y, q, steps=steps_for_quality(arch, q), seed=seed, image_offset=first[bi])
             n = x0.shape[0]
             acc[0] += psnr(y, x0) * n; acc[1] += psnr(restored, x0) * n
             acc[2] += l2(y, x0) * n; acc[3] += l2(restored, x0) * n; acc[4] += n

@@ -51,6 +51,10 @@ def test_harness_step_rule():
     # webp_inference.py:678-679 clamp(100-q, 20, 80); avif_inference.py:534-535 clamp(100-q, 15, 75)
     assert [steps_for_quality(spec.ARCH_WEBP, q) for q in (0, 10, 50, 90)] == [80, 80, 50, 20]
     assert [steps_for_quality(spec.ARCH_AVIF, q) for q in (1, 30, 90)] == [75, 70, 15]
+    # the reference computes int((100 - q) / 100 * 100) in floating point: one step fewer than 100 - q at these qualities
+    assert [steps_for_quality(spec.ARCH_WEBP, q) for q in (42, 43, 71)] == [57, 56, 28]
+    assert [steps_for_quality(spec.ARCH_AVIF, q) for q in (42, 43, 71)] == [57, 56, 28]
+    assert all(steps_for_quality(spec.ARCH_JPEG, q) == max(20, min(80, int((100 - q) / 100 * 100))) for q in range(0, 101))
 
 
 def test_harness_ssim_matches_independent_restatement():
