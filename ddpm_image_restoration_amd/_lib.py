@@ -28,7 +28,10 @@ SYMBOLS = {
     "ddpmir_create": (C.c_void_p, [C.POINTER(Config)]),
     "ddpmir_destroy": (None, [C.c_void_p]),
     "ddpmir_last_error": (C.c_char_p, [C.c_void_p]),
-    "ddpmir_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "ddpmir_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "ddpmir_weight_layout_version": (C.c_int, []),
+    "ddpmir_set_codec_library": (C.c_int, [C.c_int, C.c_char_p]),
+    "ddpmir_host_codec_roundtrip_u8": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ddpmir_weight_blob_bytes": (C.c_size_t, [C.c_void_p]),
     "ddpmir_finalize_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ddpmir_param_count": (C.c_int64, [C.c_void_p]),
@@ -81,7 +84,24 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    _bind_pillow_codec_libraries(lib)
     return lib
+
+
+def _bind_pillow_codec_libraries(lib) -> None:
+    """Point the built-in WebP / AVIF host codecs at the libwebp / libavif copies bundled with this interpreter's Pillow
+    (pillow.libs/), so the library's codec round trips are those of the reference's `pil_img.save(...)` calls with the very
+    same codec build.  Without Pillow the library falls back to $DDPMIR_LIBWEBP / $DDPMIR_LIBAVIF or the system's copies."""
+    import glob
+    try:
+        import PIL
+    except ImportError:
+        return
+    libs = os.path.join(os.path.dirname(os.path.dirname(PIL.__file__)), "pillow.libs")
+    for arch, pat in ((0, "libwebp-*.so*"), (2, "libavif-*.so*")):
+        hits = sorted(glob.glob(os.path.join(libs, pat)))
+        if hits:
+            lib.ddpmir_set_codec_library(arch, hits[0].encode())
 
 
 def check(lib, ctx, rc: int, what: str):

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libddpmir.so")
-SOURCES = ["igemm.hip", "gemm16.hip", "attention.hip", "attention_bf16.hip", "pointwise.hip", "sampler_kernels.hip", "jpeg_sim.hip", "model.hip", "eps_unet.hip", "api.hip", "ops_api.hip"]
+SOURCES = ["igemm.hip", "gemm16.hip", "attention.hip", "attention_bf16.hip", "pointwise.hip", "sampler_kernels.hip", "jpeg_sim.hip", "model.hip", "eps_unet.hip", "api.hip", "ops_api.hip", "host_codec.cpp"]
 # MFMA results feed VALU (softmax) directly: keep C/D in VGPRs instead of copying through AGPRs every tile
 VGPR_MFMA = {"attention_bf16.hip", "attention.hip", "gemm16.hip"}
 # packed-f32 VALU (v_pk_add_f32) beside MFMAs costs ~3x a scalar add on gfx950: keep the softmax sums scalar
@@ -33,23 +33,30 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
+    """experiments=True builds libddpmir_exp.so with -DDDPMIR_EXPERIMENTS: the A/B environment switches and extra kernel
+    instantiations the measurement tools under tools/ use (select it with DDPMIR_LIB_PATH); never the shipped library."""
+    if experiments:
+        return _build(os.path.join(HERE, "libddpmir_exp.so"), os.path.join(HERE, "build_exp"), ["-DDDPMIR_EXPERIMENTS"], verbose)
     if not force and not needs_build():
         return LIB
+    return _build(LIB, os.path.join(HERE, "build"), [], verbose)
+
+
+def _build(lib: str, objdir: str, defines, verbose: bool) -> str:
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []
     for src in SOURCES:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         extra = ["-ffp-contract=off"] if src in NO_CONTRACT else []
         if src in VGPR_MFMA:
             extra += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
         if src in NO_SLP:
             extra += ["-fno-slp-vectorize"]
-        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *defines, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
     for src, p in procs:
@@ -61,9 +68,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write(f"--- {src} ---\n{out}\n")
     if failed:
         raise RuntimeError("hipcc failed")
-    subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB, *objs])
-    return LIB
+    subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib, *objs, "-ldl", "-lpthread"])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))

@@ -127,9 +127,36 @@ def _shutdown_procs() -> None:
         _procs = None
 
 
-def roundtrip_u8(u8_nchw: np.ndarray, quality: int, kind: str, out: np.ndarray | None = None) -> np.ndarray:
-    """decode(encode(img, quality)) for every image of a uint8 [B,3,H,W] batch."""
+def native_roundtrip_u8(u8_nchw: np.ndarray, quality: int, kind: str, out: np.ndarray | None = None):
+    """The library's built-in host codec pool (csrc/host_codec.cpp: libwebp / libavif C APIs on a C++ thread pool; the same
+    bits as the Pillow path, tests/test_host_codec.py).  Returns None when that codec is unavailable."""
+    import ctypes as C
+    from . import _lib, spec
+    arch = {"webp": spec.ARCH_WEBP, "avif": spec.ARCH_AVIF}.get(kind)
+    if arch is None:
+        return None
+    lib = _lib.load()
+    src = np.ascontiguousarray(u8_nchw, dtype=np.uint8)
+    dst = out if (out is not None and out.flags["C_CONTIGUOUS"] and out.dtype == np.uint8) else np.empty_like(src)
+    b, _, h, w = src.shape
+    rc = lib.ddpmir_host_codec_roundtrip_u8(arch, src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p), b, h, w, int(quality))
+    if rc != 0:
+        return None
+    if out is not None and dst is not out:
+        out[...] = dst
+        return out
+    return dst
+
+
+def roundtrip_u8(u8_nchw: np.ndarray, quality: int, kind: str, out: np.ndarray | None = None, backend: str = "pillow") -> np.ndarray:
+    """decode(encode(img, quality)) for every image of a uint8 [B,3,H,W] batch.  backend="native" uses the library's codec
+    pool where it exists (WebP / AVIF) and falls back to the Pillow calls below (e.g. the reference's AVIF -> JPEG fallback
+    on an encoder error lives there)."""
     b = u8_nchw.shape[0]
+    if backend == "native":
+        res = native_roundtrip_u8(u8_nchw, quality, kind, out)
+        if res is not None:
+            return res
     if out is None:
         out = np.empty_like(u8_nchw)
     if b == 1:
@@ -149,7 +176,7 @@ def _compress(x, quality: int, kind: str):
     """[-1,1] float NCHW torch tensor -> decoded [-1,1] tensor on the same device (reference semantics)."""
     import torch
     u8 = (x * 127.5 + 127.5).clamp(0, 255).to(torch.uint8).cpu().numpy()
-    dec = torch.from_numpy(roundtrip_u8(u8, quality, kind))
+    dec = torch.from_numpy(roundtrip_u8(u8, quality, kind, backend=os.environ.get("DDPMIR_HOST_CODEC", "native")))
     return dec.to(x.device).float().div(255).sub(0.5).mul(2.0)
 
 

@@ -2,6 +2,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "eps_unet.h"
 #include "model.h"
@@ -71,13 +72,68 @@ void ddpmir_destroy(ddpmir_ctx* ctx) {
 
 const char* ddpmir_last_error(ddpmir_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
-int ddpmir_load_tensor(ddpmir_ctx* ctx, const char* name, const float* data_host, const int64_t* shape, int ndim) {
+int ddpmir_load_tensor(ddpmir_ctx* ctx, const char* name, const void* data_host, int dtype, const int64_t* shape, int ndim) {
   const bool e = ctx && ctx->eps;
   return guarded(ctx, [&] {
     if (!name || !data_host || !shape || ndim < 0 || ndim > 8) throw std::invalid_argument("load_tensor: bad argument");
-    if (e) ctx->eps->load_tensor(name, data_host, shape, ndim);
-    else ctx->impl->load_tensor(name, data_host, shape, ndim);
+    const float* f32 = static_cast<const float*>(data_host);
+    std::vector<float> wide;
+    if (dtype != DDPMIR_F32) {   // half-precision checkpoints: widen exactly
+      if (dtype != DDPMIR_BF16 && dtype != DDPMIR_F16) throw std::invalid_argument("load_tensor: dtype must be DDPMIR_F32, DDPMIR_BF16 or DDPMIR_F16");
+      int64_t n = 1;
+      for (int i = 0; i < ndim; ++i) n *= shape[i];
+      wide.resize((size_t)std::max<int64_t>(n, 0));
+      const uint16_t* h = static_cast<const uint16_t*>(data_host);
+      for (int64_t i = 0; i < n; ++i) {
+        uint32_t u;
+        if (dtype == DDPMIR_BF16) {
+          u = (uint32_t)h[i] << 16;
+        } else {
+          const uint32_t sgn = (uint32_t)(h[i] & 0x8000u) << 16, ex = (h[i] >> 10) & 0x1Fu, man = h[i] & 0x3FFu;
+          if (ex == 0) {
+            if (man == 0) u = sgn;
+            else {   // subnormal half: normalise
+              int sh = 0; uint32_t m = man;
+              while (!(m & 0x400u)) { m <<= 1; ++sh; }
+              u = sgn | ((uint32_t)(127 - 15 - sh + 1) << 23) | ((m & 0x3FFu) << 13);
+            }
+          } else if (ex == 31) u = sgn | 0x7F800000u | (man << 13);
+          else u = sgn | ((ex + 112u) << 23) | (man << 13);
+        }
+        std::memcpy(&wide[(size_t)i], &u, 4);
+      }
+      f32 = wide.data();
+    }
+    if (e) ctx->eps->load_tensor(name, f32, shape, ndim);
+    else ctx->impl->load_tensor(name, f32, shape, ndim);
   }, e);
+}
+
+int ddpmir_weight_layout_version(void) { return DDPMIR_WEIGHT_LAYOUT_VERSION; }
+
+int ddpmir_set_codec_library(int arch, const char* path) {
+  try {
+    if (!path) throw std::invalid_argument("set_codec_library: null path");
+    ddpmir::set_codec_library(arch, path);
+    return DDPMIR_OK;
+  } catch (const std::exception& e) {
+    g_create_err = e.what();
+    return DDPMIR_EINVAL;
+  }
+}
+
+int ddpmir_host_codec_roundtrip_u8(int arch, const uint8_t* in, uint8_t* out, int B, int H, int W, int quality) {
+  try {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0) throw std::invalid_argument("host_codec_roundtrip_u8: bad argument");
+    ddpmir_codec_fn fn = ddpmir::builtin_host_codec(arch);
+    if (!fn) { g_create_err = "codec: " + ddpmir::builtin_host_codec_error(); return DDPMIR_ECODEC; }
+    const int rc = fn(nullptr, in, out, B, H, W, quality);
+    if (rc != 0) { g_create_err = "codec: the built-in host codec failed with code " + std::to_string(rc); return DDPMIR_ECODEC; }
+    return DDPMIR_OK;
+  } catch (const std::exception& e) {
+    g_create_err = e.what();
+    return DDPMIR_EINVAL;
+  }
 }
 
 size_t ddpmir_weight_blob_bytes(ddpmir_ctx* ctx) {

@@ -308,11 +308,11 @@ void launch_attention(const float* qkv, float* out, int ldo, int B, int N, int C
   dim3 grid(cdiv(N, 128), heads, B), block(256);
   switch (D) {
     case 8:
-      if (getenv("DDPMIR_ATTN_F32_OLD")) { hipLaunchKernelGGL(flash_f32<8>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break; }
+      if (exp_switch("DDPMIR_ATTN_F32_OLD")) { hipLaunchKernelGGL(flash_f32<8>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break; }
       hipLaunchKernelGGL(flash_f32_t16<8>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale);
       break;
     case 16:
-      if (getenv("DDPMIR_ATTN_F32_OLD")) { hipLaunchKernelGGL(flash_f32<16>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break; }
+      if (exp_switch("DDPMIR_ATTN_F32_OLD")) { hipLaunchKernelGGL(flash_f32<16>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break; }
       hipLaunchKernelGGL(flash_f32_t16<16>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale);
       break;
     case 32: hipLaunchKernelGGL(flash_f32<32>, grid, block, 0, stream, qkv, out, ldo, N, C, qscale); break;

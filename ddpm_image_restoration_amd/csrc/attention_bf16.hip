@@ -449,12 +449,11 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
   const float qscale = 1.44269504088896340736f / sqrtf((float)D);
   if (qkv) hipLaunchKernelGGL(pack_qkv_bf16<D>, dim3(NT, heads, B), dim3(256), 0, s, qkv, Qp, KVp, Kmax, N, NT, C, qscale);
   const int nqb = (N + 128 * QS - 1) / (128 * QS);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr;
+  attr.run([] {
     DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16<D, QS, TS, WPS, DMA, DEN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SG::STAGE_BYTES + 2 * TS * 4));
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL((flash_bf16<D, QS, TS, WPS, DMA, DEN>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
                      out, ldo, N, NT, heads, nqb, BH, reinterpret_cast<__bf16*>(out16));
   DDPMIR_HIP_CHECK(hipGetLastError());
@@ -518,7 +517,8 @@ size_t attention_bf16_workspace(int B, int N, int C, int heads) {
 
 void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* workspace,
                            hipStream_t s, void* out16) {
-  static const int var = [] { const char* e = getenv("DDPMIR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // tuning knob
+#ifdef DDPMIR_EXPERIMENTS   // tile-shape A/B instantiations (tools/attn_ab*.py); the shipped library has one kernel per head_dim
+  const int var = exp_value("DDPMIR_ATTN_VARIANT");
   if (C / heads == 32 && var >= 20) {   // head_dim 32 experiments
     switch (var) {
       case 20: run_flash<32, 1, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
@@ -552,6 +552,7 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
       default: break;
     }
   }
+#endif
   switch (C / heads) {
     // head_dim <= 16 is bound by v_exp issue: two query sub-tiles per wave share every K/V fragment read and give
     // the scheduler two independent exp/pack/PV chains (A/B on one device: 7.92 vs 8.49 ms at N = 65 536)

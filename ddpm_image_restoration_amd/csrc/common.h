@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <stdexcept>
 #include <string>
 
 namespace ddpmir {
@@ -50,6 +53,31 @@ struct Status {
       throw std::runtime_error(_b);                                                                \
     }                                                                                              \
   } while (0)
+
+// Experiment switches (A/B environment variables of the measurement tools under tools/) exist only in builds made with
+// -DDDPMIR_EXPERIMENTS (build.py --experiments -> libddpmir_exp.so); the shipped library carries the production path alone.
+#ifdef DDPMIR_EXPERIMENTS
+inline bool exp_switch(const char* name) { return getenv(name) != nullptr; }
+inline int exp_value(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+#else
+constexpr bool exp_switch(const char*) { return false; }
+constexpr int exp_value(const char*) { return 0; }
+#endif
+
+// Function attributes (e.g. the dynamic LDS limit) belong to a (kernel, device) pair: contexts on different GPUs of one
+// process each need them, possibly from different threads.  One instance per kernel instantiation.
+struct PerDeviceOnce {
+  std::mutex mu;
+  unsigned long long done = 0;
+  template <typename F>
+  void run(F&& f) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("hipGetDevice failed");
+    std::lock_guard<std::mutex> g(mu);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done & bit)) { f(); done |= bit; }
+  }
+};
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -18,6 +18,14 @@
 
 #include "kernels.h"
 
+// IGemm::dbg (skip A loads / B loads / MFMAs / stores: the dissection runs of tools/gemm_inventory.py) only exists in
+// -DDDPMIR_EXPERIMENTS builds; in the shipped kernel the tests fold to constants.
+#ifdef DDPMIR_EXPERIMENTS
+#define GEMM_DBG(p) ((p).dbg)
+#else
+#define GEMM_DBG(p) 0
+#endif
+
 namespace ddpmir {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   const int nit_all = nit_main + (p.Cinb + BK - 1) / BK;
   const int nsplit = gridDim.z, sk = blockIdx.z;
   const int it0 = (int)((long long)nit_all * sk / nsplit), it1 = (int)((long long)nit_all * (sk + 1) / nsplit);
-  const int nit = (p.dbg & 16) ? 0 : it1 - it0;
+  const int nit = (GEMM_DBG(p) & 16) ? 0 : it1 - it0;
   const __bf16* A16 = reinterpret_cast<const __bf16*>(p.A16);
   const __bf16* W16 = reinterpret_cast<const __bf16*>(p.Wt16);
   const __bf16* A16b = reinterpret_cast<const __bf16*>(p.A16b);
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
     int dy = 0, dx = 0;
     if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
     const unsigned sbase = lds0 + (itl % STAGES) * STAGE;
-    if (!(p.dbg & 1))
+    if (!(GEMM_DBG(p) & 1))
 #pragma unroll
     for (int j = 0; j < AL; ++j) {
       const int c = c0 + 8 * a_chunk[j];
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
       const void* g = ok ? (const void*)(A16 + a_off[j] + (ptrdiff_t)(dy * p.W + dx) * p.lda16 + c) : (const void*)zero;
       __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sbase + (j * 256 + wave * 64) * 16), 16, 0, 0);
     }
-    if (!(p.dbg & 2))
+    if (!(GEMM_DBG(p) & 2))
 #pragma unroll
     for (int j = 0; j < BL; ++j) {
       const int c = c0 + 8 * b_chunk[j];
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
   }
 
   // ------------------------------------------------------------------------------------------ epilogue
-  if ((p.dbg & 8) && acc[0][0] != 12345.f) return;
+  if ((GEMM_DBG(p) & 8) && acc[0][0] != 12345.f) return;
   const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE || p.sel_C;
   const bool atomic = nsplit > 1;
   if (atomic) {
@@ -436,12 +444,11 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   constexpr int HN = NT < 2 ? NT : 2;
   constexpr int EPI = 4 * (NT == 4 ? 64 * 36 : 32 * (HN * 32 + 4)) * 4;
   constexpr int LDS = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  attr.run([] {
     DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<NT, BK, STAGES>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr = true;
-  }
+  });
   const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
   const int nit = p.taps * cdiv(p.Cin, BK) + cdiv(p.Cinb, BK);
   int nsplit = 1;
@@ -469,9 +476,9 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
   // ... and so does a long K loop with enough work per barrier: 3x3 convs with Cout <= 64 or K >= 2048 measured 5-15 %
   // faster at BK = 64 / two workgroups per CU than at BK = 32 / four (tools/gemm_inventory.py), 1x1 and short-K the reverse
   const int ktot = p.taps * p.Cin + p.Cinb;
-  static const bool no_longk = getenv("DDPMIR_GEMM_NO_LONGK") != nullptr;   // A/B switch
+  const bool no_longk = exp_switch("DDPMIR_GEMM_NO_LONGK");   // A/B switch
   const bool longk = !no_longk && p.taps == 9 && (NT <= 2 || ktot >= 2048);
-  const bool bk64 = (p.dbg & 32) ? true : (p.dbg & 64) ? false : (tiles < 256 || longk);
+  const bool bk64 = (GEMM_DBG(p) & 32) ? true : (GEMM_DBG(p) & 64) ? false : (tiles < 256 || longk);
   if (bk64) launch_nt<NT, 64, 2>(p, M, stream);
   else launch_nt<NT, 32, 2>(p, M, stream);
 }

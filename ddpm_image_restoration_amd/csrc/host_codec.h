@@ -1,0 +1,15 @@
+// Built-in host codec pool for the families without a device codec (host_codec.cpp).  Plain C++ (no HIP): the file also
+// builds with gcc + AddressSanitizer on the CPU (tests/test_host_codec.py::test_sanitizer_build).
+#pragma once
+#include <string>
+
+#include "../../include/ddpmir.h"
+
+namespace ddpmir {
+
+void set_codec_library(int arch, const std::string& path);
+// NULL when the codec library cannot be loaded or fails its self-check, with the reason in builtin_host_codec_error()
+ddpmir_codec_fn builtin_host_codec(int arch);
+std::string builtin_host_codec_error();
+
+}  // namespace ddpmir

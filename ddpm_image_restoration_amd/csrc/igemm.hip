@@ -504,14 +504,13 @@ void launch_bf16(const IGemm& p, int64_t M, hipStream_t stream) {
   constexpr int EPI = 4 * 32 * (NT * 32 + 4) * 4;                      // epilogue staging tile
   constexpr int LDS1 = (BM + NT * 32) * LROW16 > EPI ? (BM + NT * 32) * LROW16 : EPI;
   constexpr int LDS = 2 * (BM + NT * 32) * LROW16;
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  attr.run([] {
     DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_kernel<NT, 2>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_kernel<NT, 1>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS1));
-    attr = true;
-  }
+  });
   const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
   const int nit = p.taps * cdiv(p.Cin, BK16);
   // split K across workgroups when the output tiling alone cannot fill the 256 CUs and the epilogue is linear
@@ -520,7 +519,7 @@ void launch_bf16(const IGemm& p, int64_t M, hipStream_t stream) {
                       p.store == STORE_NHWC && (p.Cout % 4) == 0 && (!p.res || p.res != p.out || p.ldres == p.ldo);
   // (split-K with float atomics is off: this kernel only serves tiny maps now, and bf16 mode stays bit-reproducible;
   //  set DDPMIR_IGEMM_SPLITK=1 to get the old behaviour for experiments)
-  static const bool allow_split = getenv("DDPMIR_IGEMM_SPLITK") != nullptr;
+  const bool allow_split = exp_switch("DDPMIR_IGEMM_SPLITK");
   if (allow_split && linear && gx * gy < 256 && nit >= 8) {
     nsplit = std::min(std::min(16, nit / 4), cdiv(512, gx * gy));
     if (nsplit < 1) nsplit = 1;
@@ -528,7 +527,7 @@ void launch_bf16(const IGemm& p, int64_t M, hipStream_t stream) {
   if (nsplit > 1 && !(p.res && p.res == p.out))
     hipLaunchKernelGGL(zero_rows_k, dim3((unsigned)std::min<int64_t>(cdiv64(M * (p.Cout / 4), 256), 2048)), dim3(256), 0,
                        stream, p.out, p.ldo, M, p.Cout / 4);
-  static const int force = [] { const char* e = getenv("DDPMIR_IGEMM_STAGES"); return e ? atoi(e) : 0; }();
+  const int force = exp_value("DDPMIR_IGEMM_STAGES");
   const bool one = force ? force == 1 : (nit <= 18 && nsplit == 1);
   if (one) hipLaunchKernelGGL((igemm_bf16_kernel<NT, 1>), dim3(gx, gy, 1), dim3(256), LDS1, stream, p);
   else hipLaunchKernelGGL((igemm_bf16_kernel<NT, 2>), dim3(gx, gy, nsplit), dim3(256), LDS, stream, p);

@@ -153,6 +153,27 @@ void launch_fill_t(float* t, int B, int step_i, int steps, hipStream_t s);
 // Philox4x32-10 + Box-Muller standard normal, counter = global element index (independent of GPU count)
 void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s);
 
+// Per-timestep scalars of one micro-batch lane, in DEVICE memory.  Every kernel of a timestep reads the loop index i and
+// what derives from it from here, and the step's last kernel advances i, so a captured timestep (hipGraph) is replayed
+// unchanged T times with no host-side parameter update (webp_inference.py:566-600 is the loop body).
+struct StepParams {
+  int i, steps, last;                  // loop index of the step about to run; last = (i == 0): x_t = x' without noise
+  float t, noise_scale, coeff;         // t = float(i)/steps; noise_scale = t * coeff
+  unsigned long long seed_base, seed;  // Philox key of step i = seed_base + i * golden-ratio constant
+  unsigned long long rng_offset;       // Philox counter base of this lane: (global index of its first image) * 3HW / 4
+  const float* noise; long long noise_stride;   // injected noise [steps][noise_stride] (null = Philox)
+};
+void launch_step_params_set(StepParams* p, int i, int steps, float coeff, uint64_t seed_base, uint64_t rng_offset,
+                            const float* noise, int64_t noise_stride, hipStream_t s);
+void launch_step_params_advance(StepParams* p, hipStream_t s);
+void launch_fill_t_p(float* t, int B, const StepParams* p, hipStream_t s);
+void launch_randn_p(float* out, int64_t n, const StepParams* p, hipStream_t s);
+// dev_noise: Philox output for this lane (used when p->noise is null); lane_off: element offset of the lane inside one
+// step of the injected noise tensor
+void launch_ddrm_update_p(const float* x_theta, const uint8_t* dec_u8, const float* y, const float* dev_noise, int64_t lane_off,
+                          float* x_out, int64_t n, float eta, float eta_b, float one_minus_eta_b, const StepParams* p,
+                          hipStream_t s);
+
 // on-device JPEG encode->decode round trip, bit-exact to libjpeg-turbo/Pillow defaults (jpeg_sim.hip)
 size_t jpeg_sim_workspace(int B, int H, int W);
 void launch_jpeg_roundtrip(const uint8_t* in, uint8_t* out, uint8_t* scratch, int B, int H, int W, int quality,
@@ -166,6 +187,10 @@ struct DftPlan {           // device twiddle tables
 // forward 2-D DFT of `planes` real images [P][H][W] -> re/im [P][H][W]; tmp_* are [P][H][W] scratch
 void launch_dft2_forward(const float* x, float* re, float* im, float* tmp_re, float* tmp_im, int P,
                          const DftPlan& d, hipStream_t s);
+// unit phase of fft2(y) computed in double (rows, then columns fused with the normalisation); tmp_*: [P][H][W] doubles
+struct DftPlan64 { const double* cos_h; const double* sin_h; int H; const double* cos_w; const double* sin_w; int W; };
+void launch_ref_unit_phase_f64(const float* y, float* ure, float* uim, double* tmp_re, double* tmp_im, int P, const DftPlan64& d,
+                               hipStream_t s);
 // unit phase of the reference spectrum: (re,im)/|.|, (1,0) where |.|==0
 void launch_unit_phase(float* re, float* im, int64_t n, hipStream_t s);
 // out = alpha*x + (1-alpha) * Re(ifft2(|X| * U))   (X = re/im in, U = unit phase)

@@ -6,7 +6,11 @@
 #include <vector>
 
 #include "../../include/ddpmir.h"
+#include "host_codec.h"
 #include "kernels.h"
+
+// layout version of the packed weight blob (layout_weights): bump on any change of order, padding or derived tensors
+#define DDPMIR_WEIGHT_LAYOUT_VERSION 2
 
 namespace ddpmir {
 
@@ -56,6 +60,24 @@ struct BlockW {
   // AVIF frequency block
   AvifTransformW at;
   ConvW ms1[4], ms3[4], cc0, cc2, ep0, ep2;
+};
+
+// scalars baked into the launch arguments of a timestep (a captured timestep graph is valid for one such set)
+struct LoopConsts {
+  bool dev_codec = false;
+  int quality = 0;
+  float eta = 0.f, eta_b = 0.f, one_minus_eta_b = 0.f;
+  double alpha = 0.0;
+  bool operator==(const LoopConsts& o) const {
+    return dev_codec == o.dev_codec && quality == o.quality && eta == o.eta && eta_b == o.eta_b &&
+           one_minus_eta_b == o.one_minus_eta_b && alpha == o.alpha;
+  }
+};
+
+struct GraphSlot {      // one captured launch sequence; `warm` = it has run eagerly once (lazy function attributes are set)
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  bool warm = false;
 };
 
 struct ArchConsts {
@@ -129,9 +151,13 @@ class Context {
     float *boost = nullptr, *boost2 = nullptr, *constmix = nullptr;
     // sampler state
     float *s_xt = nullptr, *s_theta = nullptr, *s_y = nullptr, *s_noise = nullptr, *s_t = nullptr;
+    StepParams* sp = nullptr;          // [2] per-lane step scalars on the device
+    GraphSlot g_front[2], g_back[2][2];   // captured timestep halves per lane (back: without / with the phase fix)
+    LoopConsts lg_key; int lg_nl = 0;
     uint8_t *s_u8 = nullptr, *s_dec = nullptr, *s_jpeg = nullptr;
     float* dft[10] = {nullptr};
     float *tw_ch = nullptr, *tw_sh = nullptr, *tw_cw = nullptr, *tw_sw = nullptr;
+    double *tw64_ch = nullptr, *tw64_sh = nullptr, *tw64_cw = nullptr, *tw64_sw = nullptr, *dft64_re = nullptr, *dft64_im = nullptr;
     // graph
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
     float *g_x = nullptr, *g_t = nullptr, *g_cl = nullptr, *g_out = nullptr;
@@ -152,6 +178,11 @@ class Context {
   void conv(const ConvW& cw, IGemm p, hipStream_t s);
   void phase_fix(float* x, int B, int H, int W, double alpha, hipStream_t s, size_t off);   // uses cached unit phase of y
   void phase_prepare(const float* y, int B, int H, int W, hipStream_t s, size_t off);
+  void step_front(int l, int nb, const LoopConsts& c, hipStream_t s);
+  void step_back(int l, int nb, bool with_phase, const LoopConsts& c, hipStream_t s);
+  template <typename F> void run_or_replay(GraphSlot& g, bool use_graph, hipStream_t s, F&& body);
+  void drop_loop_graphs();
+  double codec_host_ms_ = 0.0; int64_t codec_calls_ = 0;   // host time spent inside the codec callback ("codec_host" class)
   int fb_ = 0;                      // batch of the forward being enqueued (<= plan_.B; micro-batch lanes)
   hipEvent_t lane_ev_[2] = {nullptr, nullptr};
 

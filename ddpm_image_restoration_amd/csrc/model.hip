@@ -3,6 +3,7 @@
 #include "model.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -274,6 +275,7 @@ size_t Context::weight_blob_bytes() {
 }
 
 void Context::finalize_weights(void* dev_blob, int fill) {
+  if (finalized_) throw std::logic_error("finalize_weights called twice on one context");
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
   const size_t bytes = weight_blob_bytes();
   if (dev_blob) {
@@ -349,14 +351,18 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
   const size_t n_img = (size_t)B * 3 * H * W;
   p.s_xt = a.take<float>(n_img); p.s_theta = a.take<float>(n_img); p.s_y = a.take<float>(n_img);
   p.s_noise = a.take<float>(n_img + 4); p.s_t = a.take<float>(B);
+  p.sp = a.take<StepParams>(2);
   p.s_u8 = a.take<uint8_t>(n_img); p.s_dec = a.take<uint8_t>(n_img);
   p.s_jpeg = a.take<uint8_t>(jpeg_sim_workspace(B, H, W));
   for (int i = 0; i < 10; ++i) p.dft[i] = a.take<float>(n_img);
   p.tw_ch = a.take<float>(H); p.tw_sh = a.take<float>(H); p.tw_cw = a.take<float>(W); p.tw_sw = a.take<float>(W);
+  p.tw64_ch = a.take<double>(H); p.tw64_sh = a.take<double>(H); p.tw64_cw = a.take<double>(W); p.tw64_sw = a.take<double>(W);
+  p.dft64_re = a.take<double>(n_img); p.dft64_im = a.take<double>(n_img);
   p.g_x = a.take<float>(n_img); p.g_out = a.take<float>(n_img); p.g_t = a.take<float>(B); p.g_cl = a.take<float>(B);
 }
 
 void Context::free_plan() {
+  drop_loop_graphs();
   if (plan_.gexec) (void)hipGraphExecDestroy(plan_.gexec);
   if (plan_.graph) (void)hipGraphDestroy(plan_.graph);
   if (plan_.base) (void)hipFree(plan_.base);
@@ -391,6 +397,20 @@ void Context::ensure_plan(int B, int H, int W) {
   };
   tw(H, plan_.tw_ch, plan_.tw_sh);
   tw(W, plan_.tw_cw, plan_.tw_sw);
+  auto tw64 = [&](int n, double* dc, double* ds) {
+    std::vector<double> c(n), s(n);
+    for (int i = 0; i < n; ++i) {
+      // exact at the multiples of a quarter turn, so purely real / imaginary bins stay exactly so
+      const int q = (4 * i) % n == 0 ? (4 * i) / n : -1;
+      const double ang = 2.0 * M_PI * (double)i / (double)n;
+      c[i] = q == 0 ? 1.0 : q == 1 ? 0.0 : q == 2 ? -1.0 : q == 3 ? 0.0 : std::cos(ang);
+      s[i] = q == 0 ? 0.0 : q == 1 ? 1.0 : q == 2 ? 0.0 : q == 3 ? -1.0 : std::sin(ang);
+    }
+    DDPMIR_HIP_CHECK(hipMemcpy(dc, c.data(), n * 8, hipMemcpyHostToDevice));
+    DDPMIR_HIP_CHECK(hipMemcpy(ds, s.data(), n * 8, hipMemcpyHostToDevice));
+  };
+  tw64(H, plan_.tw64_ch, plan_.tw64_sh);
+  tw64(W, plan_.tw64_cw, plan_.tw64_sw);
   std::vector<float> mix(B, k.head_mix);
   DDPMIR_HIP_CHECK(hipMemcpy(plan_.constmix, mix.data(), B * 4, hipMemcpyHostToDevice));
   size_t need = (size_t)B * 3 * H * W;
@@ -436,14 +456,21 @@ void Context::prof_collect() {
 void Context::profile_enable(int enable) {
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
   if (enable) {
-    if (cfg.use_graph) throw std::logic_error("profiling needs use_graph = 0 (events cannot bracket nodes of a replayed graph)");
+    // (with use_graph = 1 the loop and predict() launch eagerly while profiling is on: events cannot bracket graph nodes)
     prof_collect();
     for (int i = 0; i < 3; ++i) { prof_ms_[i] = 0; prof_n_[i] = 0; prof_flops_[i] = 0; }
+    codec_host_ms_ = 0.0; codec_calls_ = 0;
   }
   prof_on_ = enable != 0;
 }
 void Context::profile_read(const std::string& cls, double* ms, int64_t* launches, double* flops) {
   prof_collect();
+  if (cls == "codec_host") {   // host milliseconds inside the codec callback of the sampling loop, and its call count
+    if (ms) *ms = codec_host_ms_;
+    if (launches) *launches = codec_calls_;
+    if (flops) *flops = 0.0;
+    return;
+  }
   int c = cls == "attention_l0" ? PROF_ATTN_L0 : cls == "attention" ? PROF_ATTN : cls == "forward" ? PROF_FWD : -1;
   if (c < 0) throw std::invalid_argument("unknown profile class " + cls);
   if (ms) *ms = prof_ms_[c];
@@ -570,7 +597,7 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   c1.out = p.hA; c1.ldo = C;
   // norm2's statistics come out of conv1's epilogue where the launch is not split-K (levels 0-3 at 256x256); the
   // accumulator is cleared by the norm1-apply pass that runs just before
-  static const bool no_gn_fuse = getenv("DDPMIR_NO_GN_FUSE") != nullptr;
+  const bool no_gn_fuse = exp_switch("DDPMIR_NO_GN_FUSE");
   IGemm probe = c1; probe.Cout = bw.conv1.cout16; probe.Cin = bw.conv1.cin16; probe.taps = bw.conv1.taps;
   const bool fuse_gn = !no_gn_fuse && gemm16_can_fuse_gn(probe, gn_groups(C));
   launch_gn_apply16(in, ldin, B, HW, bw.cinp, p.sc1, p.sh1, ACT_NONE, p.a16, cin8, bw.has_shortcut ? p.x16 : nullptr,
@@ -587,7 +614,7 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   conv16(bw.conv2, c2, s);
   if (attn) {
     // head_dim 16 levels: the projection's epilogue writes the attention operand images itself (no fp32 qkv round trip)
-    static const bool no_fuse = getenv("DDPMIR_NO_QKV_FUSE") != nullptr;
+    const bool no_fuse = exp_switch("DDPMIR_NO_QKV_FUSE");
     const bool prepack = !no_fuse && attention_bf16_prepack_supported(HW, C, k.heads);
     IGemm q = g; q.A16 = p.hB16; q.lda16 = C;
     if (prepack) {
@@ -613,7 +640,7 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
     launch_gn_apply16(p.hB, C, B, HW, C, nullptr, nullptr, ACT_NONE, p.hB16, C, nullptr, 0, s);
   }
   // frequency block: DCT -> masked bf16 operands -> gates -> S (bf16 only, it feeds conv_out alone)
-  static const bool split_gates = getenv("DDPMIR_SPLIT_GATES") != nullptr;   // A/B: the four separate gate GEMMs
+  const bool split_gates = exp_switch("DDPMIR_SPLIT_GATES");   // A/B: the four separate gate GEMMs
   if (cfg.arch == DDPMIR_ARCH_AVIF) {
     freq_avif(bw, H, W, s);                                            // -> plan_.S (fp32)
     launch_gn_apply16(p.S, C, B, HW, C, nullptr, nullptr, ACT_NONE, p.S16, C, nullptr, 0, s);
@@ -640,7 +667,7 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   // conv_out + residual; a 1x1 shortcut conv rides along as a second K segment of the same GEMM (identity shortcuts
   // are the plain fp32 residual)
   IGemm co = g; co.A16 = p.S16; co.lda16 = C; co.out = dest; co.ldo = lddest;
-  static const bool split_sc = getenv("DDPMIR_SPLIT_SHORTCUT") != nullptr;   // A/B: separate shortcut GEMM
+  const bool split_sc = exp_switch("DDPMIR_SPLIT_SHORTCUT");   // A/B: separate shortcut GEMM
   if (bw.has_shortcut && !split_sc) {
     co.A16b = p.x16; co.lda16b = cin8; co.Wt16b = bw.shortcut.w16; co.Cinb = bw.shortcut.cin16;
     conv16(bw.conv_out, co, s, bw.co_bias);
@@ -769,7 +796,7 @@ void Context::predict(const float* x, const float* t, const float* cl, float* ou
   hipStream_t st = own ? stream_ : s;
   Plan& p = plan_;
   const size_t n_img = (size_t)B * 3 * H * W;
-  if (cfg.use_graph) {
+  if (cfg.use_graph && !prof_on_) {
     // fixed-address staging buffers so the captured graph is replayable for any caller pointers
     DDPMIR_HIP_CHECK(hipMemcpyAsync(p.g_x, x, n_img * 4, hipMemcpyDeviceToDevice, st));
     DDPMIR_HIP_CHECK(hipMemcpyAsync(p.g_t, t, B * 4, hipMemcpyDeviceToDevice, st));
@@ -799,11 +826,10 @@ void Context::predict(const float* x, const float* t, const float* cl, float* ou
 // `off` = element offset of the image sub-batch inside the per-plan DFT buffers (micro-batch lanes of the loop)
 void Context::phase_prepare(const float* y, int B, int H, int W, hipStream_t s, size_t off) {
   Plan& p = plan_;
-  DftPlan d{p.tw_ch, p.tw_sh, H, p.tw_cw, p.tw_sw, W};
   const int P = B * 3;
-  // dft[0], dft[1] = unit phase of fft2(y)
-  launch_dft2_forward(y, p.dft[0] + off, p.dft[1] + off, p.dft[4] + off, p.dft[5] + off, P, d, s);
-  launch_unit_phase(p.dft[0] + off, p.dft[1] + off, (int64_t)P * H * W, s);
+  // dft[0], dft[1] = unit phase of fft2(y), from a double-precision transform (see sampler_kernels.hip)
+  DftPlan64 d{p.tw64_ch, p.tw64_sh, H, p.tw64_cw, p.tw64_sw, W};
+  launch_ref_unit_phase_f64(y, p.dft[0] + off, p.dft[1] + off, p.dft64_re + off, p.dft64_im + off, P, d, s);
 }
 
 void Context::phase_fix(float* x, int B, int H, int W, double alpha, hipStream_t s, size_t off) {
@@ -835,24 +861,85 @@ void Context::jpeg_roundtrip(const uint8_t* in, uint8_t* out, int B, int H, int 
 }
 
 // ------------------------------------------------------------------------------------------------ DDRM loop
+// One timestep of webp_inference.py:566-600 for micro-batch lane l, in two halves around the codec round trip.  All
+// per-step scalars (i, t, the noise scale and key, the last-step flag) live in plan_.sp[l] on the device, and the back
+// half ends by advancing them, so both halves are the same launch sequence for every i: they run either eagerly or as
+// captured hipGraphs (cfg.use_graph) -- the same kernels with the same arguments, hence bit-identical results.
+void Context::step_front(int l, int nb, const LoopConsts& c, hipStream_t s) {
+  Plan& p = plan_;
+  const size_t nh = (size_t)nb * 3 * p.H * p.W;
+  fb_ = nb;
+  launch_fill_t_p(p.s_t + l * nb, nb, p.sp + l, s);
+  forward(p.s_xt + l * nh, p.s_t + l * nb, p.s_t + l * nb, p.s_theta + l * nh, s);
+  launch_quantize_u8(p.s_theta + l * nh, p.s_u8 + l * nh, (int64_t)nh, s);
+  if (c.dev_codec)   // JPEG round trip stays on the device: no PCIe hop, no host synchronisation inside the loop
+    launch_jpeg_roundtrip(p.s_u8 + l * nh, p.s_dec + l * nh, p.s_jpeg, nb, p.H, p.W, c.quality, s);
+  else
+    DDPMIR_HIP_CHECK(hipMemcpyAsync(pin_in_ + l * nh, p.s_u8 + l * nh, nh, hipMemcpyDeviceToHost, s));
+}
+
+void Context::step_back(int l, int nb, bool with_phase, const LoopConsts& c, hipStream_t s) {
+  Plan& p = plan_;
+  const size_t nh = (size_t)nb * 3 * p.H * p.W;
+  if (!c.dev_codec) DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_dec + l * nh, pin_out_ + l * nh, nh, hipMemcpyHostToDevice, s));
+  // counter = (step, global element index): results do not depend on how the batch is sharded
+  launch_randn_p(p.s_noise + l * nh, (int64_t)nh, p.sp + l, s);
+  launch_ddrm_update_p(p.s_theta + l * nh, p.s_dec + l * nh, p.s_y + l * nh, p.s_noise + l * nh, (int64_t)(l * nh),
+                       p.s_xt + l * nh, (int64_t)nh, c.eta, c.eta_b, c.one_minus_eta_b, p.sp + l, s);
+  if (with_phase) phase_fix(p.s_xt + l * nh, nb, p.H, p.W, c.alpha, s, l * nh);
+  launch_step_params_advance(p.sp + l, s);
+}
+
+template <typename F>
+void Context::run_or_replay(GraphSlot& g, bool use_graph, hipStream_t s, F&& body) {
+  if (!use_graph || !g.warm) {   // first execution is eager: lazily initialised function attributes must not land in a capture
+    body();
+    g.warm = true;
+    return;
+  }
+  if (!g.exec) {
+    DDPMIR_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    try {
+      body();
+    } catch (...) {
+      hipGraph_t broken = nullptr;
+      (void)hipStreamEndCapture(s, &broken);
+      if (broken) (void)hipGraphDestroy(broken);
+      throw;
+    }
+    DDPMIR_HIP_CHECK(hipStreamEndCapture(s, &g.graph));
+    DDPMIR_HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+  }
+  DDPMIR_HIP_CHECK(hipGraphLaunch(g.exec, s));
+}
+
 void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, int quality, int steps, double eta,
                                double eta_b, const ddpmir_loop_opts* opts) {
   if (!finalized_) throw std::logic_error("sample before finalize_weights");
   if (steps <= 0) throw std::invalid_argument("steps must be positive");
   if (!opts) throw std::invalid_argument("loop options are required");
-  const bool dev_codec = opts->codec == nullptr;
-  if (dev_codec && cfg.arch != DDPMIR_ARCH_JPEG)
-    throw std::invalid_argument("a codec callback is required: only the JPEG family has a built-in device codec");
+  LoopConsts c;
+  ddpmir_codec_fn codec = opts->codec;
+  void* codec_user = opts->codec_user;
+  c.dev_codec = codec == nullptr && cfg.arch == DDPMIR_ARCH_JPEG;
+  if (!codec && !c.dev_codec) {   // WebP / AVIF with no callback: the built-in host codec pool (libwebp / libavif C API)
+    codec = builtin_host_codec(cfg.arch);
+    codec_user = nullptr;
+    if (!codec) throw std::runtime_error("codec: no callback given and the built-in host codec library could not be loaded (" +
+                                         builtin_host_codec_error() + ")");
+  }
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
   ensure_plan(B, H, W);
   Plan& p = plan_;
   hipStream_t s = stream_;
   const size_t n = (size_t)B * 3 * H * W;
+  c.quality = quality;
+  c.eta = (float)eta; c.eta_b = (float)eta_b;
+  c.one_minus_eta_b = (float)(1.0 - eta_b);   // Python forms (1 - eta_b) in double (webp_inference.py:592)
+  c.alpha = opts->phase_alpha >= 0.0 ? opts->phase_alpha : k.phase_alpha;
   const float coeff = opts->noise_coeff >= 0.0 ? (float)opts->noise_coeff : k.noise_coeff;
   const int phase_q = opts->phase_q >= 0 ? opts->phase_q : k.phase_q;
   const int every = opts->phase_every > 0 ? opts->phase_every : k.phase_every;
-  const double alpha = opts->phase_alpha >= 0.0 ? opts->phase_alpha : k.phase_alpha;
-  const float one_minus_eta_b = (float)(1.0 - eta_b);   // Python forms (1 - eta_b) in double (webp_inference.py:592)
   const bool do_phase = quality < phase_q;
   DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_y, y, n * 4, hipMemcpyDeviceToDevice, s));     // y = x_t.clone()
   DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_xt, y, n * 4, hipMemcpyDeviceToDevice, s));
@@ -863,46 +950,34 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
   // lanes that are software-pipelined -- while the host runs the codec of lane A, the GPU runs the U-Net
   // forward of lane B, and lane A's next forward is enqueued before lane B's codec starts.  Images are
   // independent, so the results are those of the unsplit batch.  The device JPEG codec needs no lanes.
-  static const bool no_overlap = getenv("DDPMIR_NO_OVERLAP") != nullptr;
-  const int nl = (!dev_codec && B >= 2 && (B % 2) == 0 && !no_overlap) ? 2 : 1;
+  const int nl = (!c.dev_codec && B >= 2 && (B % 2) == 0 && !exp_switch("DDPMIR_NO_OVERLAP")) ? 2 : 1;
   const int nb = B / nl;
   const size_t nh = (size_t)nb * 3 * H * W;                 // elements per lane
   if (do_phase)
     for (int l = 0; l < nl; ++l) phase_prepare(p.s_y + l * nh, nb, H, W, s, l * nh);
+  for (int l = 0; l < nl; ++l)
+    launch_step_params_set(p.sp + l, i_first, steps, coeff, opts->seed,
+                           (opts->image_offset + (uint64_t)l * nb) * (uint64_t)(3 * H * W) / 4, opts->noise, (int64_t)n, s);
 
-  auto enqueue_forward = [&](int l, int i) {   // G(l, i): t, U-Net forward, uint8 quantise, (D2H)
-    fb_ = nb;
-    launch_fill_t(p.s_t + l * nb, nb, i, steps, s);
-    forward(p.s_xt + l * nh, p.s_t + l * nb, p.s_t + l * nb, p.s_theta + l * nh, s);
-    launch_quantize_u8(p.s_theta + l * nh, p.s_u8 + l * nh, (int64_t)nh, s);
-    if (!dev_codec) {
-      DDPMIR_HIP_CHECK(hipMemcpyAsync(pin_in_ + l * nh, p.s_u8 + l * nh, nh, hipMemcpyDeviceToHost, s));
-      DDPMIR_HIP_CHECK(hipEventRecord(lane_ev_[l], s));
-    }
+  // captured timesteps are valid for one set of baked-in scalars; anything else (seed, noise, offsets, i) is in plan_.sp
+  const bool graphs = cfg.use_graph && !prof_on_;   // HIP-event spans cannot bracket nodes of a replayed graph
+  if (graphs && !(p.lg_key == c && p.lg_nl == nl)) { drop_loop_graphs(); p.lg_key = c; p.lg_nl = nl; }
+
+  auto front = [&](int l) {   // G(l, i): t, U-Net forward, uint8 quantise, device codec or D2H
+    run_or_replay(p.g_front[l], graphs, s, [&] { step_front(l, nb, c, s); });
+    if (!c.dev_codec) DDPMIR_HIP_CHECK(hipEventRecord(lane_ev_[l], s));
   };
   auto codec_and_update = [&](int l, int i) {  // C(l, i) on the host, then U(l, i) on the stream
-    if (dev_codec) {
-      // JPEG round trip stays on the device: no PCIe hop, no host synchronisation inside the loop
-      launch_jpeg_roundtrip(p.s_u8 + l * nh, p.s_dec + l * nh, p.s_jpeg, nb, H, W, quality, s);
-    } else {
+    if (!c.dev_codec) {
       DDPMIR_HIP_CHECK(hipEventSynchronize(lane_ev_[l]));
-      int rc = opts->codec(opts->codec_user, pin_in_ + l * nh, pin_out_ + l * nh, nb, H, W, quality);
+      const auto t0 = std::chrono::steady_clock::now();
+      int rc = codec(codec_user, pin_in_ + l * nh, pin_out_ + l * nh, nb, H, W, quality);
+      codec_host_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      codec_calls_ += 1;
       if (rc != 0) throw std::runtime_error("codec callback failed with code " + std::to_string(rc));
-      DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_dec + l * nh, pin_out_ + l * nh, nh, hipMemcpyHostToDevice, s));
     }
-    const float* noise = nullptr;
-    if (i > 0) {
-      if (opts->noise) noise = opts->noise + (size_t)i * n + l * nh;
-      else {
-        // counter = (step, global element index): results do not depend on how the batch is sharded
-        launch_randn(p.s_noise + l * nh, (int64_t)nh, opts->seed + (uint64_t)i * 0x9E3779B97F4A7C15ull,
-                     (opts->image_offset + (uint64_t)l * nb) * (uint64_t)(3 * H * W) / 4, s);
-        noise = p.s_noise + l * nh;
-      }
-    }
-    launch_ddrm_update(p.s_theta + l * nh, p.s_dec + l * nh, p.s_y + l * nh, noise, p.s_xt + l * nh, (int64_t)3 * H * W, nb,
-                       (float)eta, (float)eta_b, one_minus_eta_b, coeff, i, steps, i == 0 ? 1 : 0, s);
-    if (i > 0 && do_phase && (i % every) == 0) phase_fix(p.s_xt + l * nh, nb, H, W, alpha, s, l * nh);
+    const bool with_phase = i > 0 && do_phase && (i % every) == 0;
+    run_or_replay(p.g_back[l][with_phase ? 1 : 0], graphs, s, [&] { step_back(l, nb, with_phase, c, s); });
     if (opts->trace) {
       float* tr = opts->trace + (size_t)(i_first - i) * 2 * n + l * nh;
       DDPMIR_HIP_CHECK(hipMemcpyAsync(tr, p.s_theta + l * nh, nh * 4, hipMemcpyDeviceToDevice, s));
@@ -911,11 +986,11 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
   };
 
   try {
-    for (int l = 0; l < nl; ++l) enqueue_forward(l, i_first);
+    for (int l = 0; l < nl; ++l) front(l);
     for (int i = i_first; i >= i_last; --i)
       for (int l = 0; l < nl; ++l) {
         codec_and_update(l, i);
-        if (i - 1 >= i_last) enqueue_forward(l, i - 1);
+        if (i - 1 >= i_last) front(l);
       }
   } catch (...) {
     fb_ = B;
@@ -925,6 +1000,16 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
   fb_ = B;
   DDPMIR_HIP_CHECK(hipMemcpyAsync(out, p.s_xt, n * 4, hipMemcpyDeviceToDevice, s));
   DDPMIR_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void Context::drop_loop_graphs() {
+  Plan& p = plan_;
+  auto drop = [](GraphSlot& g) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+    g = GraphSlot();
+  };
+  for (int l = 0; l < 2; ++l) { drop(p.g_front[l]); drop(p.g_back[l][0]); drop(p.g_back[l][1]); }
 }
 
 }  // namespace ddpmir

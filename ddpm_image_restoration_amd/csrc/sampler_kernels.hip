@@ -43,6 +43,52 @@ __global__ void fill_t_k(float* t, int B, float v) {
   if (b < B) t[b] = v;
 }
 
+// ---- per-timestep scalars in device memory (StepParams, kernels.h): the kernels of one timestep read the loop index and
+// everything derived from it from there, so the captured timestep graph is replayed unchanged for every i.
+// t = float(i)/steps and noise_scale = t*coeff are single correctly-rounded fp32 operations, exactly what the host
+// formed before (webp_inference.py:568,588).
+__device__ __forceinline__ void step_params_derive(StepParams* p) {
+  p->t = __fdiv_rn((float)p->i, (float)p->steps);
+  p->noise_scale = __fmul_rn(p->t, p->coeff);
+  p->last = p->i == 0 ? 1 : 0;
+  p->seed = p->seed_base + (unsigned long long)p->i * 0x9E3779B97F4A7C15ull;
+}
+__global__ void step_params_set_k(StepParams* p, int i, int steps, float coeff, unsigned long long seed_base,
+                                  unsigned long long rng_offset, const float* noise, long long noise_stride) {
+  p->i = i; p->steps = steps; p->coeff = coeff; p->seed_base = seed_base; p->rng_offset = rng_offset;
+  p->noise = noise; p->noise_stride = noise_stride;
+  step_params_derive(p);
+}
+__global__ void step_params_advance_k(StepParams* p) {   // last node of a timestep: i -> i - 1
+  p->i -= 1;
+  step_params_derive(p);
+}
+__global__ void fill_t_p_k(float* t, int B, const StepParams* __restrict__ p) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) t[b] = p->t;
+}
+// DDRM update with the step scalars (and, for injected noise, the [steps][...] base pointer) read from *p
+__global__ void ddrm_update_p_k(const float* __restrict__ x_theta, const uint8_t* __restrict__ dec_u8,
+                                const float* __restrict__ y, const float* __restrict__ dev_noise, long long lane_off,
+                                float* __restrict__ x_out, int64_t n, float eta, float eta_b, float one_minus_eta_b,
+                                const StepParams* __restrict__ p) {
+  const int last = p->last;
+  const float noise_scale = p->noise_scale;
+  const float* noise = p->noise ? p->noise + (long long)p->i * p->noise_stride + lane_off : dev_noise;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float dec = __fmul_rn(__fsub_rn(__fdiv_rn((float)dec_u8[i], 255.0f), 0.5f), 2.0f);
+    float th = x_theta[i];
+    float xp = __fadd_rn(__fsub_rn(th, dec), y[i]);
+    if (last) {
+      x_out[i] = xp;
+    } else {
+      float rnd = __fmul_rn(noise[i], noise_scale);
+      float mix = __fadd_rn(__fmul_rn(eta_b, xp), __fmul_rn(one_minus_eta_b, th));
+      x_out[i] = __fadd_rn(mix, __fmul_rn(eta, rnd));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- Philox4x32-10
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
                                              uint32_t k1) {
@@ -53,7 +99,11 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
   c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
 
-__global__ void randn_k(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+__global__ void randn_k(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset, const StepParams* __restrict__ sp) {
+  if (sp) {   // timestep form: key and counter base from the device-side step scalars; nothing to draw at the last step
+    if (sp->last || sp->noise) return;                                   // ... or with injected noise
+    seed = sp->seed; offset = sp->rng_offset;
+  }
   const int64_t nq = (n + 3) / 4;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
     uint64_t ctr = offset + (uint64_t)q;
@@ -169,6 +219,51 @@ __global__ __launch_bounds__(256) void dft_cols_k(const float* __restrict__ in_r
   }
 }
 
+// ---- arg(fft2(ref)) in double precision.  The phase of a bin whose magnitude sits at rounding level (a JPEG-decoded y can
+// have a spectrum bin that is zero up to 1e-7) is decided by the error of the transform, not by the data: an fp32 direct
+// DFT (error ~ N eps) then disagrees with the reference's FFT (error ~ log N eps) about the sign of such a bin and the image
+// leaves the reference trajectory at its first phase fix.  This transform runs once per sample() call, so it is simply
+// done in double: rows, then columns fused with the normalisation to the unit phase (fp32 out).
+__global__ void dft_rows_f64_k(const float* __restrict__ in, double* __restrict__ out_re, double* __restrict__ out_im, int W,
+                               int64_t nrows, const double* __restrict__ cs, const double* __restrict__ sn) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= nrows * W) return;
+  const int64_t row = gid / W;
+  const int v = (int)(gid - row * W);
+  const float* src = in + row * W;
+  double ar = 0.0, ai = 0.0;
+  int idx = 0;
+  for (int x = 0; x < W; ++x) {
+    const double a = (double)src[x];
+    ar = fma(a, cs[idx], ar);
+    ai = fma(-a, sn[idx], ai);          // e^{-2 pi i v x / W}
+    idx += v; if (idx >= W) idx -= W;
+  }
+  out_re[gid] = ar; out_im[gid] = ai;
+}
+__global__ void dft_cols_unit_f64_k(const double* __restrict__ in_re, const double* __restrict__ in_im, float* __restrict__ ure,
+                                    float* __restrict__ uim, int H, int W, int64_t total, const double* __restrict__ cs,
+                                    const double* __restrict__ sn) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (plane, u, x), x fastest
+  if (gid >= total) return;
+  const int x = (int)(gid % W);
+  const int u = (int)((gid / W) % H);
+  const int64_t p = gid / ((int64_t)W * H);
+  const double* br = in_re + p * H * W + x;
+  const double* bi = in_im + p * H * W + x;
+  double ar = 0.0, ai = 0.0;
+  int idx = 0;
+  for (int y = 0; y < H; ++y) {
+    const double vr = br[(size_t)y * W], vi = bi[(size_t)y * W], c = cs[idx], sv = -sn[idx];
+    ar += vr * c - vi * sv;
+    ai += vr * sv + vi * c;
+    idx += u; if (idx >= H) idx -= H;
+  }
+  const double mag = sqrt(ar * ar + ai * ai);
+  if (mag > 0.0) { ure[gid] = (float)(ar / mag); uim[gid] = (float)(ai / mag); }
+  else { ure[gid] = 1.f; uim[gid] = 0.f; }    // angle(0) = atan2(0,0) = 0
+}
+
 __global__ void unit_phase_k(float* re, float* im, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float r = re[i], m = im[i];
@@ -231,7 +326,33 @@ void launch_fill_t(float* t, int B, int step_i, int steps, hipStream_t s) {
 }
 
 void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s) {
-  hipLaunchKernelGGL(randn_k, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, out, n, seed, offset);
+  hipLaunchKernelGGL(randn_k, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, out, n, seed, offset, (const StepParams*)nullptr);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_step_params_set(StepParams* p, int i, int steps, float coeff, uint64_t seed_base, uint64_t rng_offset,
+                            const float* noise, int64_t noise_stride, hipStream_t s) {
+  hipLaunchKernelGGL(step_params_set_k, dim3(1), dim3(1), 0, s, p, i, steps, coeff, (unsigned long long)seed_base,
+                     (unsigned long long)rng_offset, noise, (long long)noise_stride);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+void launch_step_params_advance(StepParams* p, hipStream_t s) {
+  hipLaunchKernelGGL(step_params_advance_k, dim3(1), dim3(1), 0, s, p);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+void launch_fill_t_p(float* t, int B, const StepParams* p, hipStream_t s) {
+  hipLaunchKernelGGL(fill_t_p_k, dim3(cdiv(B, 64)), dim3(64), 0, s, t, B, p);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+void launch_randn_p(float* out, int64_t n, const StepParams* p, hipStream_t s) {
+  hipLaunchKernelGGL(randn_k, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, out, n, (uint64_t)0, (uint64_t)0, p);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+void launch_ddrm_update_p(const float* x_theta, const uint8_t* dec_u8, const float* y, const float* dev_noise, int64_t lane_off,
+                          float* x_out, int64_t n, float eta, float eta_b, float one_minus_eta_b, const StepParams* p,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(ddrm_update_p_k, dim3(grid_for(n)), dim3(256), 0, s, x_theta, dec_u8, y, dev_noise, (long long)lane_off,
+                     x_out, n, eta, eta_b, one_minus_eta_b, p);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
@@ -239,9 +360,10 @@ void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStre
 static void dft_rows_lds(int W) {
   const size_t bytes = (size_t)(2 * DFT_RB + 2) * W * sizeof(float);
   if (bytes > 160 * 1024) throw std::invalid_argument("phase_consistency: image width too large for the DFT row kernel");
-  if (bytes > 64 * 1024)
+  if (bytes > 64 * 1024) {   // per launch: the limit depends on W (rare: rows wider than ~900 pixels)
     DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dft_rows_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)bytes));
+  }
 }
 
 void launch_dft2_forward(const float* x, float* re, float* im, float* tmp_re, float* tmp_im, int P, const DftPlan& d,
@@ -276,6 +398,16 @@ void launch_phase_apply_inverse(const float* x, const float* xre, const float* x
                      tmp2_re, tmp2_im, tmp_re, tmp_im, W, nrows, d.cos_w, d.sin_w, 1.0f, 1.0f / (float)W);
   // python: alpha * x + (1 - alpha) * adjusted ; (1 - alpha) is evaluated in double by the caller
   hipLaunchKernelGGL(blend_k, dim3(grid_for(n)), dim3(256), 0, s, x, tmp_re, out, alpha, one_minus_alpha, n);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+void launch_ref_unit_phase_f64(const float* y, float* ure, float* uim, double* tmp_re, double* tmp_im, int P, const DftPlan64& d,
+                               hipStream_t s) {
+  const int64_t total = (int64_t)P * d.H * d.W;
+  const unsigned blocks = (unsigned)cdiv64(total, 256);
+  hipLaunchKernelGGL(dft_rows_f64_k, dim3(blocks), dim3(256), 0, s, y, tmp_re, tmp_im, d.W, (int64_t)P * d.H, d.cos_w, d.sin_w);
+  hipLaunchKernelGGL(dft_cols_unit_f64_k, dim3(blocks), dim3(256), 0, s, (const double*)tmp_re, (const double*)tmp_im, ure, uim,
+                     d.H, d.W, total, d.cos_h, d.sin_h);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

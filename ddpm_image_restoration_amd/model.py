@@ -21,6 +21,26 @@ def _torch():
     return torch
 
 
+def _host_array(v):
+    """(contiguous host ndarray, DDPMIR dtype code) of a state-dict entry.  bf16 / fp16 checkpoints cross the C ABI in their
+    storage type (ddpmir_load_tensor widens them exactly); everything else is converted to float32 here."""
+    if hasattr(v, "detach"):
+        torch = _torch()
+        t = v.detach().cpu().contiguous()
+        if t.dtype == torch.bfloat16:
+            return t.view(torch.int16).numpy(), 1
+        if t.dtype == torch.float16:
+            return t.numpy(), 2
+        return np.ascontiguousarray(t.float().numpy(), dtype=np.float32), 0
+    a = np.asarray(v)
+    if a.dtype == np.float16:
+        return np.ascontiguousarray(a), 2
+    return np.ascontiguousarray(a, dtype=np.float32), 0
+
+
+PACKED_MAGIC = b"DDPMIRW\x00"
+
+
 class _RestorationModel:
     ARCH = spec.ARCH_WEBP
 
@@ -48,8 +68,12 @@ class _RestorationModel:
     # ---- nn.Module look-alikes used by the reference call sites
     def to(self, device):
         torch = _torch()
-        if torch.device(device).type != "cuda":
+        d = torch.device(device)
+        if d.type != "cuda":
             raise RuntimeError("the restoration model runs on a HIP device only")
+        if d.index is not None and d.index != (self.device.index or 0):
+            raise RuntimeError(f"this model lives on {self.device}; create it with device={d} instead of moving it "
+                               "(weights and workspace are bound to one GPU)")
         return self
 
     def eval(self):
@@ -87,19 +111,22 @@ class _RestorationModel:
 
     def _load_one(self, name, v):
         want = spec.state_spec(self.ARCH)
-        arr = v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, dtype=np.float32)
-        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        arr, code = _host_array(v)
         if name not in want or tuple(arr.shape) != tuple(want[name]):
             raise RuntimeError(f"unexpected tensor or shape for {name}: {tuple(arr.shape)}")
         shape = (C.c_int64 * arr.ndim)(*arr.shape)
-        rc = self._lib.ddpmir_load_tensor(self._ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim)
+        rc = self._lib.ddpmir_load_tensor(self._ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), code, shape, arr.ndim)
         _lib.check(self._lib, self._ctx, rc, f"load_tensor({name})")
 
     def finalize(self, blob=None, fill: bool = True):
         """blob: optional torch uint8 CUDA tensor of weight_blob_bytes() bytes that will hold the packed weights
         (used for the RCCL broadcast in dist.py)."""
+        if self._loaded:
+            raise RuntimeError("weights already finalized for this model object")
         ptr = None
         if blob is not None:
+            if blob.device != self.device or blob.numel() < self.weight_blob_bytes():
+                raise RuntimeError("finalize: the blob must be a uint8 tensor of weight_blob_bytes() bytes on the model's device")
             self._blob = blob
             ptr = C.c_void_p(blob.data_ptr())
         rc = self._lib.ddpmir_finalize_weights(self._ctx, ptr, int(fill))
@@ -114,15 +141,32 @@ class _RestorationModel:
             raise RuntimeError("load_state_dict() first")
         if self._blob is None:
             raise RuntimeError("save_packed needs the blob to be caller-owned: use convert_checkpoint()")
-        np.save(path, self._blob.cpu().numpy(), allow_pickle=False)
+        np.save(path, np.concatenate([self._packed_header(), self._blob.cpu().numpy()]), allow_pickle=False)
+
+    def _packed_header(self) -> np.ndarray:
+        """64 bytes in front of a packed blob file: magic, blob layout version, model family, arithmetic mode,
+        attn_min_level, payload byte count -- a blob only loads into the configuration it was packed for."""
+        import struct
+        h = PACKED_MAGIC + struct.pack("<4iq", self._lib.ddpmir_weight_layout_version(), self._cfg.arch, self._cfg.dtype,
+                                       self._cfg.attn_min_level, self.weight_blob_bytes())
+        return np.frombuffer(h.ljust(64, b"\0"), dtype=np.uint8)
 
     def load_packed(self, path: str):
-        """Adopt a blob written by save_packed() (same model family and dtype): no per-tensor repacking."""
+        """Adopt a blob written by save_packed(): no per-tensor repacking.  The file's header must name this model's
+        family, arithmetic mode, attention levels and the library's current blob layout version."""
         torch = _torch()
         arr = np.load(path if path.endswith(".npy") else path + ".npy", allow_pickle=False)
-        if arr.dtype != np.uint8 or arr.size != self.weight_blob_bytes():
-            raise RuntimeError(f"packed blob does not match this model: {arr.size} vs {self.weight_blob_bytes()} bytes")
-        blob = torch.from_numpy(arr).to(self.device)
+        want = self._packed_header()
+        if arr.dtype != np.uint8 or arr.size < 64 or bytes(arr[:8]) != PACKED_MAGIC:
+            raise RuntimeError("not a packed weight blob written by save_packed()")
+        if not np.array_equal(arr[:64], want):
+            import struct
+            got = struct.unpack("<4iq", bytes(arr[8:32]))
+            raise RuntimeError("packed blob does not match this model: file (layout, arch, dtype, attn_min_level, bytes) = "
+                               f"{got}, model = {struct.unpack('<4iq', bytes(want[8:32]))}")
+        if arr.size - 64 != self.weight_blob_bytes():
+            raise RuntimeError("packed blob is truncated")
+        blob = torch.from_numpy(arr[64:].copy()).to(self.device)
         self.finalize(blob=blob, fill=False)
         return self
 
@@ -248,7 +292,7 @@ class UNetDenoiser:
             if tuple(arr.shape) != tuple(want[name]):
                 raise RuntimeError(f"shape mismatch for {name}")
             shape = (C.c_int64 * arr.ndim)(*arr.shape)
-            rc = self._lib.ddpmir_load_tensor(self._ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim)
+            rc = self._lib.ddpmir_load_tensor(self._ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), 0, shape, arr.ndim)
             _lib.check(self._lib, self._ctx, rc, f"load_tensor({name})")
         _lib.check(self._lib, self._ctx, self._lib.ddpmir_finalize_weights(self._ctx, None, 1), "finalize_weights")
         self._loaded = True

@@ -1,8 +1,10 @@
 """Drop-in samplers: DDRM{WebP,JPEG,AVIF}Sampler(model).sample(x_t, quality, steps, eta, eta_b).
 
 Reference: webp_inference.py:553-602, svd.ipynb c0:391-440, avif_inference.py:410-459.  The T-step loop runs
-inside libddpmir.so (ddpmir_ddrm_sample_loop); the codec round trip of each step is a host callback into
-Pillow -- the same library calls the reference makes -- unless the model family has a device codec.
+inside libddpmir.so (ddpmir_ddrm_sample_loop).  The codec round trip of each step is built into the library: JPEG on the
+device (bit-exact libjpeg-turbo simulator), WebP / AVIF through libwebp / libavif's C APIs on a C++ thread pool (the
+copies bundled with this interpreter's Pillow, bit-identical to the reference's PIL calls).  host_codec="pillow" routes
+it through a callback into Pillow instead -- literally the library calls the reference makes.
 """
 from __future__ import annotations
 
@@ -38,9 +40,11 @@ class _DDRMSampler:
         return _lib.CODEC_FN(cb)
 
     def sample(self, x_t, quality, steps=100, eta=0.85, eta_b=1.0, noise=None, seed=0, image_offset=0,
-               trace=False, device_codec=None, start_step=-1, num_steps=0):
+               trace=False, device_codec=None, start_step=-1, num_steps=0, host_codec=None):
         """noise: optional tensor [steps,B,3,H,W]; noise[i] replaces torch.randn_like at loop index i.
-        trace=True additionally returns a [steps,2,B,3,H,W] tensor of (x_theta, x_t) per executed step."""
+        trace=True additionally returns a [steps,2,B,3,H,W] tensor of (x_theta, x_t) per executed step.
+        device_codec (JPEG): None/True = on-device codec, False = host codec.  host_codec: "native" (the library's
+        libwebp / libavif pool; default for WebP / AVIF) or "pillow" (callback into Pillow; the only host JPEG codec)."""
         import torch
         m = self.model
         m.eval()
@@ -49,9 +53,15 @@ class _DDRMSampler:
         out = torch.empty_like(x)
         opts = _lib.LoopOpts()
         cb = self._codec_cb()
-        # JPEG has a bit-exact device codec (no host round trip); WebP / AVIF always call back into Pillow
+        # JPEG has a bit-exact device codec (no host round trip); WebP / AVIF use the library's host pool or the callback
         use_dev = (self.KIND == "jpeg") if device_codec is None else bool(device_codec)
-        opts.codec = _lib.CODEC_FN(0) if (use_dev and self.KIND == "jpeg") else cb
+        if host_codec is None:
+            import os
+            host_codec = os.environ.get("DDPMIR_HOST_CODEC", "native")
+        if host_codec not in ("native", "pillow"):
+            raise ValueError("host_codec must be 'native' or 'pillow'")
+        builtin = (use_dev and self.KIND == "jpeg") or (host_codec == "native" and self.KIND in ("webp", "avif"))
+        opts.codec = _lib.CODEC_FN(0) if builtin else cb
         opts.codec_user = None
         nz = None
         if noise is not None:

@@ -35,6 +35,7 @@ extern "C" {
 
 #define DDPMIR_F32 0
 #define DDPMIR_BF16 1
+#define DDPMIR_F16 2         /* storage type of checkpoint tensors only (ddpmir_load_tensor) */
 
 typedef struct ddpmir_ctx ddpmir_ctx;
 
@@ -44,7 +45,9 @@ typedef struct ddpmir_config {
   int attn_min_level;  /* 0 = self-attention in all 13 blocks (the reference, webp_inference.py:317-321);
                           5 = bottleneck blocks only (the variant BASELINE.json's configs describe) */
   int device;          /* HIP device ordinal */
-  int use_graph;       /* 1 = replay the U-Net forward as a captured hipGraph */
+  int use_graph;       /* 1 = replay captured hipGraphs: the U-Net forward in ddpmir_predict, and in ddpmir_ddrm_sample_loop the
+                          whole timestep {t, forward, quantise, codec or D2H | H2D, noise, DDRM update, phase fix} with the
+                          per-step scalars in a device-side parameter block (bit-identical to the eager launches) */
 } ddpmir_config;
 
 /* replaces: WebPDiffusionModel().to(device)  (webp_inference.py:618) */
@@ -53,13 +56,15 @@ void ddpmir_destroy(ddpmir_ctx* ctx);
 const char* ddpmir_last_error(ddpmir_ctx* ctx);   /* ctx may be NULL: error of the last failed create */
 
 /* replaces: model.load_state_dict(ckpt['model_state_dict'])  (webp_inference.py:621-627).
- * Call once per state_dict entry (torch does the unpickling), then finalize.  data_host: float32, C order. */
-int ddpmir_load_tensor(ddpmir_ctx* ctx, const char* name, const float* data_host, const int64_t* shape, int ndim);
+ * Call once per state_dict entry (torch does the unpickling), then finalize.  data_host: C order, element type `dtype`
+ * = DDPMIR_F32 | DDPMIR_BF16 | DDPMIR_F16 (checkpoints saved in half precision are widened to fp32 exactly). */
+int ddpmir_load_tensor(ddpmir_ctx* ctx, const char* name, const void* data_host, int dtype, const int64_t* shape, int ndim);
 /* repack (OIHW -> [tap][Cout][Cin]) and upload; errors list missing names.  If dev_blob != NULL the packed
  * weights live in that caller-owned device buffer of ddpmir_weight_blob_bytes() bytes (fill=1: upload into it;
  * fill=0: adopt contents already there, e.g. after an RCCL broadcast from rank 0). */
 size_t ddpmir_weight_blob_bytes(ddpmir_ctx* ctx);
 int ddpmir_finalize_weights(ddpmir_ctx* ctx, void* dev_blob, int fill);
+int ddpmir_weight_layout_version(void);            /* bumped whenever the packed blob layout changes (checked by converters) */
 int64_t ddpmir_param_count(ddpmir_ctx* ctx);       /* sum(p.numel()) -- the harness prints it */
 
 /* replaces: x_theta = model(x_t, t, compression_level)  (webp_inference.py:577; north_star's predict_noise()).
@@ -73,8 +78,19 @@ int ddpmir_predict(ddpmir_ctx* ctx, const float* x, const float* t, const float*
 typedef int (*ddpmir_codec_fn)(void* user, const uint8_t* in_u8_nchw, uint8_t* out_u8_nchw, int B, int H, int W,
                                int quality);
 
+/* Built-in codecs (what `codec == NULL` selects in the sampling loop): JPEG = the bit-exact on-device libjpeg-turbo
+ * simulator; WebP / AVIF = a C++ thread pool calling libwebp / libavif through their C APIs with the settings Pillow uses
+ * (bit-identical to the reference's PIL calls with the same library build).  The libraries are opened at run time:
+ * ddpmir_set_codec_library(DDPMIR_ARCH_WEBP | DDPMIR_ARCH_AVIF, path) names the file (the Python host passes the copy
+ * bundled with its Pillow); otherwise $DDPMIR_LIBWEBP / $DDPMIR_LIBAVIF, then the system's libwebp.so.7 / libavif.so.16. */
+int ddpmir_set_codec_library(int arch, const char* path);
+/* out = decode(encode(in, quality)) with the built-in HOST codec of a family, uint8 NCHW in host memory (no GPU, no
+ * context): replaces webp_compress / avif_compress when degrading inputs (webp_inference.py:669). */
+int ddpmir_host_codec_roundtrip_u8(int arch, const uint8_t* in_u8_nchw_host, uint8_t* out_u8_nchw_host, int B, int H, int W,
+                                   int quality);
+
 typedef struct ddpmir_loop_opts {
-  ddpmir_codec_fn codec;      /* NULL = built-in on-device codec simulator (JPEG only) */
+  ddpmir_codec_fn codec;      /* NULL = the family's built-in codec (see above) */
   void* codec_user;
   const float* noise;         /* optional device pointer [steps][B][3][H][W]: noise[i] is drawn at loop index i
                                  (replaces torch.randn_like, webp_inference.py:589); NULL = Philox(seed) */
@@ -113,7 +129,8 @@ int ddpmir_jpeg_roundtrip_u8(ddpmir_ctx* ctx, const uint8_t* in_u8_nchw, uint8_t
 /* HIP-event timing of kernel classes on the context's stream (bench.py's roofline block).  enable=1 brackets
  * every launch of the profiled classes with events; read returns the accumulated device milliseconds, launch
  * count and algorithmic FLOPs since the last enable.  Classes: "attention_l0" (self-attention over all H*W
- * tokens of the full-resolution blocks), "attention" (all 13), "forward" (whole U-Net forwards). */
+ * tokens of the full-resolution blocks), "attention" (all 13), "forward" (whole U-Net forwards), "codec_host" (HOST
+ * milliseconds spent inside the codec callback / built-in pool of the sampling loop, and the number of calls). */
 int ddpmir_profile_enable(ddpmir_ctx* ctx, int enable);
 int ddpmir_profile_read(ddpmir_ctx* ctx, const char* cls, double* ms, int64_t* launches, double* flops);
 const char* ddpmir_version(void);

@@ -3,7 +3,10 @@
  * load the state dict tensor by tensor, run one forward (webp_inference.py:577) and a few DDRM steps with the on-device
  * JPEG codec, and write both results to a file that tests/test_c_abi_client.py compares with the Python binding.
  *
- *   client <weights.bin> <input.bin> <output.bin>
+ *   client <weights.bin> <input.bin> <output.bin> [family: 0 WebP | 1 JPEG (default) | 2 AVIF]
+ * The sampling loop runs with codec == NULL: the on-device JPEG codec, or for WebP / AVIF the library's built-in host codec
+ * pool (libwebp / libavif located through $DDPMIR_LIBWEBP / $DDPMIR_LIBAVIF or the system's copies) -- no callback, so a
+ * plain-C caller needs nothing but this header.
  * weights.bin: repeated { int32 name_len; char name[]; int32 ndim; int64 shape[ndim]; float data[prod(shape)] }
  * input.bin:   int32 B, H, W, quality, steps; float x[B*3*H*W]; float t[B]; float cl[B]
  * output.bin:  float x_theta[B*3*H*W]; float x_restored[B*3*H*W]
@@ -23,10 +26,10 @@
 static int read_exact(FILE* f, void* dst, size_t n) { return fread(dst, 1, n, f) == n; }
 
 int main(int argc, char** argv) {
-  if (argc != 4) { fprintf(stderr, "usage: client weights.bin input.bin output.bin\n"); return 2; }
+  if (argc != 4 && argc != 5) { fprintf(stderr, "usage: client weights.bin input.bin output.bin [family]\n"); return 2; }
   ddpmir_config cfg;
   memset(&cfg, 0, sizeof cfg);
-  cfg.arch = DDPMIR_ARCH_JPEG; cfg.dtype = DDPMIR_F32; cfg.attn_min_level = 0; cfg.device = 0; cfg.use_graph = 0;
+  cfg.arch = argc == 5 ? atoi(argv[4]) : DDPMIR_ARCH_JPEG; cfg.dtype = DDPMIR_F32; cfg.attn_min_level = 0; cfg.device = 0; cfg.use_graph = 0;
   ddpmir_ctx* ctx = ddpmir_create(&cfg);
   if (!ctx) { fprintf(stderr, "create failed: %s\n", ddpmir_last_error(NULL)); return 4; }
 
@@ -44,7 +47,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < ndim; ++i) numel *= shape[i];
     float* data = (float*)malloc((size_t)numel * 4 + 4);
     if (!data || !read_exact(fw, data, (size_t)numel * 4)) { fprintf(stderr, "short read on %s\n", name); return 2; }
-    CHECK_RC(ctx, ddpmir_load_tensor(ctx, name, data, shape, ndim));
+    CHECK_RC(ctx, ddpmir_load_tensor(ctx, name, data, DDPMIR_F32, shape, ndim));
     free(data);
     ++n_tensors;
   }

@@ -34,13 +34,28 @@ def test_c_client_compiles_against_the_public_header(tmp_path):
     _build_client(tmp_path)
 
 
+def _pillow_codec_env():
+    import glob
+    import PIL
+    libs = os.path.join(os.path.dirname(os.path.dirname(PIL.__file__)), "pillow.libs")
+    env = dict(os.environ)
+    for var, pat in (("DDPMIR_LIBWEBP", "libwebp-*.so*"), ("DDPMIR_LIBAVIF", "libavif-*.so*")):
+        hits = sorted(glob.glob(os.path.join(libs, pat)))
+        if hits:
+            env[var] = hits[0]
+    return env
+
+
 @pytest.mark.gpu
-def test_c_client_matches_python_binding(tmp_path):
+@pytest.mark.parametrize("arch,name", [(spec.ARCH_JPEG, "jpeg"), (spec.ARCH_WEBP, "webp")])
+def test_c_client_matches_python_binding(arch, name, tmp_path):
+    """JPEG: device codec.  WebP: the sampling loop with NO codec callback -- the library's built-in libwebp pool -- from a
+    process that has neither Python nor Pillow in it; equal, bit for bit, to the Python binding with the Pillow callback."""
     import torch
-    from ddpm_image_restoration_amd.model import JPEGDiffusionModel
-    from ddpm_image_restoration_amd.sampler import DDRMJPEGSampler
+    from ddpm_image_restoration_amd.model import MODEL_BY_ARCH
+    from ddpm_image_restoration_amd.sampler import SAMPLER_BY_ARCH
     exe = _build_client(tmp_path)
-    sd = synth.synth_state_dict(spec.ARCH_JPEG, 0)
+    sd = synth.synth_state_dict(arch, 0)
     wpath, ipath, opath = str(tmp_path / "w.bin"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(wpath, "wb") as f:
         for name, v in sd.items():
@@ -54,14 +69,14 @@ def test_c_client_matches_python_binding(tmp_path):
     t = np.array([0.25, 0.75], np.float32)
     with open(ipath, "wb") as f:
         f.write(struct.pack("<5i", B, H, W, q, steps)); f.write(x.tobytes()); f.write(t.tobytes()); f.write(t.tobytes())
-    r = subprocess.run([exe, wpath, ipath, opath], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, wpath, ipath, opath, str(arch)], capture_output=True, text=True, timeout=300, env=_pillow_codec_env())
     assert r.returncode == 0, r.stdout + r.stderr
     assert "params 114398409" in r.stdout and "expected error" in r.stdout
     got = np.fromfile(opath, dtype=np.float32).reshape(2, B, 3, H, W)
-    m = JPEGDiffusionModel(device=torch.device("cuda", 0))
+    m = MODEL_BY_ARCH[arch](device=torch.device("cuda", 0))
     m.load_state_dict(sd)
     xt = torch.from_numpy(x).cuda()
     tt = torch.from_numpy(t).cuda()
     assert np.array_equal(got[0], m(xt, tt, tt).cpu().numpy())
-    want = DDRMJPEGSampler(m).sample(xt, q, steps=steps, seed=7).cpu().numpy()
+    want = SAMPLER_BY_ARCH[arch](m).sample(xt, q, steps=steps, seed=7, host_codec="pillow").cpu().numpy()
     assert np.array_equal(got[1], want)

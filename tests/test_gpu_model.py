@@ -94,9 +94,98 @@ def test_sampler_teacher_forced_golden(name, arch, golden, models):
 
 
 @pytest.mark.parametrize("name,arch", ARCHS)
+def test_sampler_teacher_forced_bf16(name, arch, golden, models):
+    """The benchmarked arithmetic (bf16 matrix-core operands) along the reference trajectories: fed the reference's own x_t
+    at every kept step, x_theta stays within SURVEY.md H2's teacher-forced budget (2e-2 max, 2e-3 mean; measured
+    0.8-1.4e-2 max, 1.5-1.7e-3 mean for all three families, tools/parity_r2.py)."""
+    g = golden(name)
+    m = models(arch, dtype="bf16")
+    steps, b = int(g["samp_steps"]), g["samp_y"].shape[0]
+    for i in g["samp_keep"]:
+        t = (np.full((b,), int(i), np.float32) / np.float32(steps)).astype(np.float32)
+        th = m(tt(g[f"samp_xt_in_{int(i)}"]), tt(t), tt(t)).cpu().numpy()
+        e = np.abs(th - g[f"samp_theta_{int(i)}"])
+        assert e.max() < 2e-2 and e.mean() < 2e-3, (int(i), e.max(), e.mean())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_timestep_graph_replay_matches_eager_device_codec(dtype, models):
+    """north_star: the T-step loop as a captured hipGraph.  use_graph=True replays {t, U-Net forward, uint8 quantise, device
+    JPEG, Philox noise, DDRM update (+ phase fix), step advance} with the per-step scalars in a device-side parameter block;
+    the eager loop launches the same kernels with the same arguments, so the results are bit-identical -- with device noise,
+    with injected noise, across the phase-fix steps (q10: every 5th index) and through the final no-noise step."""
+    import torch
+    from ddpm_image_restoration_amd.sampler import DDRMJPEGSampler
+    y = tt(O.compress(synth.synth_images(3, 32, seed=81), 10, "jpeg"))
+    se, sg = DDRMJPEGSampler(models(spec.ARCH_JPEG, dtype=dtype)), DDRMJPEGSampler(models(spec.ARCH_JPEG, dtype=dtype, use_graph=True))
+    a, ta = se.sample(y, 10, steps=12, seed=9, image_offset=5, trace=True)
+    b, tb = sg.sample(y, 10, steps=12, seed=9, image_offset=5, trace=True)
+    assert torch.equal(a, b) and torch.equal(ta, tb)
+    assert torch.equal(sg.sample(y, 10, steps=12, seed=9, image_offset=5), a)          # replay of the cached graphs
+    assert not torch.equal(sg.sample(y, 10, steps=12, seed=10, image_offset=5), a)     # the seed lives in the parameter block
+    noise = tt(synth.synth_noise(7, 3, 32, 32, seed=12))
+    assert torch.equal(se.sample(y, 10, steps=7, noise=noise), sg.sample(y, 10, steps=7, noise=noise))
+    # other baked-in scalars (quality -> quantisation tables, no phase fix at q50) re-capture
+    y50 = tt(O.compress(synth.synth_images(3, 32, seed=81), 50, "jpeg"))
+    assert torch.equal(se.sample(y50, 50, steps=6, seed=2), sg.sample(y50, 50, steps=6, seed=2))
+    # a slice of a longer schedule, as bench.py times it
+    kw = dict(steps=1000, start_step=996, num_steps=4, seed=4)
+    assert torch.equal(se.sample(y, 10, **kw), sg.sample(y, 10, **kw))
+
+
+def test_timestep_graph_replay_matches_eager_host_codec(models):
+    """Host-codec families: each of the two software-pipelined micro-batch lanes replays its own pair of captured
+    half-steps around the codec callback."""
+    import torch
+    from ddpm_image_restoration_amd.sampler import DDRMWebPSampler
+    y = tt(O.compress(synth.synth_images(4, 32, seed=82), 10, "webp"))
+    a = DDRMWebPSampler(models(spec.ARCH_WEBP)).sample(y, 10, steps=11, seed=3)
+    b = DDRMWebPSampler(models(spec.ARCH_WEBP, use_graph=True)).sample(y, 10, steps=11, seed=3)
+    assert torch.equal(a, b)
+    c = DDRMWebPSampler(models(spec.ARCH_WEBP, use_graph=True)).sample(y[:3], 10, steps=11, seed=3)   # odd batch: one lane
+    assert torch.equal(c, a[:3])
+
+
+def test_two_contexts_in_one_process_run_concurrently(synth_state):
+    """include/ddpmir.h: "a context is bound to one GPU and is not thread-safe; different contexts may run concurrently".
+    Two contexts (own streams, own workspaces) driven from two host threads at the same time give what they give alone."""
+    import threading
+    import torch
+    from ddpm_image_restoration_amd.model import JPEGDiffusionModel, WebPDiffusionModel
+    from ddpm_image_restoration_amd.sampler import DDRMJPEGSampler, DDRMWebPSampler
+    dev = torch.device("cuda", 0)
+    ma = JPEGDiffusionModel(device=dev, dtype="bf16"); ma.load_state_dict(synth_state(spec.ARCH_JPEG))
+    mb = WebPDiffusionModel(device=dev); mb.load_state_dict(synth_state(spec.ARCH_WEBP))
+    ya = tt(O.compress(synth.synth_images(2, 64, seed=91), 10, "jpeg"))
+    yb = tt(O.compress(synth.synth_images(2, 32, seed=92), 10, "webp"))
+    sa, sb = DDRMJPEGSampler(ma), DDRMWebPSampler(mb)
+    ra, rb = sa.sample(ya, 10, steps=10, seed=1), sb.sample(yb, 10, steps=10, seed=2)
+    got, errs = {}, []
+
+    def run(key, s, y, seed):
+        try:
+            for _ in range(3):
+                got[key] = s.sample(y, 10, steps=10, seed=seed)
+        except Exception as e:   # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=run, args=("a", sa, ya, 1)), threading.Thread(target=run, args=("b", sb, yb, 2))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert torch.equal(got["a"], ra) and torch.equal(got["b"], rb)
+
+
+@pytest.mark.parametrize("name,arch", ARCHS)
 def test_sampler_end_to_end_golden(name, arch, golden, models):
-    """Full trajectory with injected noise and the host codec callback: PSNR equal to 2 decimals, pixels
-    within 1e-3 except where a uint8 truncation flipped (reported, must be rare)."""
+    """Full trajectories with injected noise and the host codec callback against the reference's: EVERY image stays within
+    1e-3 of the reference at every kept step and at the end (measured 2-5e-6 for all three families), restored PSNR equal to
+    2 decimals.
+    The loop is chaotic through `.to(uint8)` truncation + lossy codec, but an fp32 rounding-level difference
+    in x_theta only flips single uint8 pixels (about one per step and batch here), which the q10 codecs absorb.  What did
+    throw one JPEG image off in round 1 was the phase fix: fft2(y) of that image has a bin that is zero up to 6e-8, and the
+    phase of such a bin is decided by the transform's rounding; arg(fft2(y)) now comes from a double-precision transform
+    (test_phase_fix_of_a_numerically_zero_bin)."""
     from ddpm_image_restoration_amd.sampler import SAMPLER_BY_ARCH
     g = golden(name)
     m = models(arch)
@@ -105,23 +194,89 @@ def test_sampler_end_to_end_golden(name, arch, golden, models):
     out, tr = SAMPLER_BY_ARCH[arch](m).sample(tt(g["samp_y"]), q, steps=steps, noise=tt(noise), trace=True,
                                               device_codec=False)
     out, tr = out.cpu().numpy(), tr.cpu().numpy()
-    first = steps - 1
-    assert np.abs(tr[0, 0] - g[f"samp_theta_{first}"]).max() < TOL
-    # The loop is chaotic through `.to(uint8)` truncation + lossy codec: an fp32 rounding-level
-    # difference (2e-6 here) that lands on an integer boundary changes a codec block and that image leaves the
-    # reference trajectory.  Images that never hit such a boundary must track to 1e-3; at most one may leave.
+    for i in (int(v) for v in g["samp_keep"]):
+        assert np.abs(tr[steps - 1 - i, 0] - g[f"samp_theta_{i}"]).max() < TOL, i
+        if i < steps - 1:
+            assert np.abs(tr[steps - 2 - i, 1] - g[f"samp_xt_in_{i}"]).max() < TOL, i
     x0 = g["samp_x0"]
     per_img = np.abs(out - g["samp_final"]).reshape(b, -1).max(axis=1)
-    tracking = per_img < TOL
-    assert tracking.sum() >= b - 1, per_img
-    assert round(O.psnr(out[tracking], x0[tracking]), 2) == round(O.psnr(g["samp_final"][tracking], x0[tracking]), 2)
-    assert abs(O.psnr(out, x0) - O.psnr(g["samp_final"], x0)) < 0.05
+    assert (per_img < TOL).all(), per_img
+    assert round(O.psnr(out, x0), 2) == round(O.psnr(g["samp_final"], x0), 2)
     # q50 run: no phase fix, JPEG 4:4:4
     steps2, q2 = int(g["samp2_steps"]), int(g["samp2_q"])
     n2 = synth.synth_noise(steps2, 2, 32, 32, seed=8)
     out2 = SAMPLER_BY_ARCH[arch](m).sample(tt(g["samp2_y"]), q2, steps=steps2, noise=tt(n2), device_codec=False).cpu().numpy()
     per2 = np.abs(out2 - g["samp2_final"]).reshape(2, -1).max(axis=1)
-    assert (per2 < TOL).sum() >= 1, per2
+    assert (per2 < TOL).all(), per2
+    assert round(O.psnr(out2, x0[:2]), 2) == round(O.psnr(g["samp2_final"], x0[:2]), 2)
+
+
+@pytest.mark.parametrize("R,n_batches,bs", [(32, 2, 256), (64, 1, 128)])
+def test_restored_psnr_bf16_mode_equals_fp32_mode(R, n_batches, bs, models):
+    """north_star's "identical PSNR to 2 decimals" for the arithmetic the benchmark runs: JPEG q10, the harness' full step
+    schedule (80 steps), device noise, bf16 mode against fp32 parity mode on the same degraded images.  The loop is chaotic
+    (H2), so single images differ -- measured over 1024 images at 32x32: per-image PSNR difference mean +0.010 dB, std 0.13,
+    max 0.52; over 256 images at 64x64: mean -0.001, std 0.06, max 0.20 (tools/parity_r2.py psnrN) -- a zero-mean scatter:
+    the mean restored PSNR of the two modes agrees to within its standard error, i.e. to 2 decimals over a test set."""
+    from ddpm_image_restoration_amd import harness
+    from ddpm_image_restoration_amd.sampler import DDRMJPEGSampler
+    import torch
+    s32, s16 = DDRMJPEGSampler(models(spec.ARCH_JPEG)), DDRMJPEGSampler(models(spec.ARCH_JPEG, dtype="bf16"))
+    steps = harness.steps_for_quality(spec.ARCH_JPEG, 10)
+    d = []
+    for k in range(n_batches):
+        x0 = synth.synth_images(bs, R, seed=900 + 10 * R + k)
+        y = harness.COMPRESS[spec.ARCH_JPEG](torch.from_numpy(x0), 10).cuda()
+        r32 = s32.sample(y, 10, steps=steps, seed=3, image_offset=k * bs).cpu().numpy()
+        r16 = s16.sample(y, 10, steps=steps, seed=3, image_offset=k * bs).cpu().numpy()
+
+        def psnr_each(a):
+            a01, b01 = np.clip(a * 0.5 + 0.5, 0, 1), np.clip(x0 * 0.5 + 0.5, 0, 1)
+            return -10 * np.log10(((a01 - b01) ** 2).reshape(bs, -1).mean(axis=1) + 1e-8)
+        d.append(psnr_each(r16) - psnr_each(r32))
+    d = np.concatenate(d)
+    se = d.std() / np.sqrt(d.size)
+    print(f"{R}x{R}, {d.size} images: bf16 - fp32 restored PSNR mean {d.mean():+.4f} dB (standard error {se:.4f}), max |d| {np.abs(d).max():.3f}")
+    assert abs(d.mean()) < 0.02, d.mean()            # 3.5 standard errors at 32x32 (N = 512), 3.7 at 64x64 (N = 128)
+    assert np.abs(d).max() < 1.0                     # no image falls out: the scatter is that of the chaotic loop
+    assert d.std() < 0.25
+
+
+def test_sampler_jpeg_every_step_49_to_39(golden, models):
+    """tests/golden/jpeg_steps49_39.npz holds x_t and x_theta of the reference for EVERY step i = 49 ... 39 of the config-1
+    run (the stretch with two phase fixes, i = 45 and 40, where round 1 lost image 1): all four images track."""
+    import os
+    from ddpm_image_restoration_amd.sampler import DDRMJPEGSampler
+    g = golden("jpeg")
+    gs = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_steps49_39.npz"))
+    steps, q, b = int(g["samp_steps"]), int(g["samp_q"]), g["samp_y"].shape[0]
+    noise = synth.synth_noise(steps, b, 32, 32, seed=7)
+    _, tr = DDRMJPEGSampler(models(spec.ARCH_JPEG)).sample(tt(g["samp_y"]), q, steps=steps, noise=tt(noise), trace=True,
+                                                          num_steps=11)
+    tr = tr.cpu().numpy()
+    for i in range(49, 38, -1):
+        assert np.abs(tr[49 - i, 0] - gs[f"theta_{i}"]).max() < TOL, i
+        if i < 49:
+            assert np.abs(tr[48 - i, 1] - gs[f"xt_in_{i}"]).max() < TOL, i
+
+
+def test_phase_fix_of_a_numerically_zero_bin(golden, models):
+    """phase_consistency (webp_inference.py:531-550) takes arg(fft2(ref)).  Image 1 of the JPEG golden batch has a spectrum
+    bin of magnitude 6e-8 (exactly representable inputs that cancel): the reference's FFT returns +1.2e-7 there, phase 0.
+    A transform with fp32 direct-summation error (1e-5) gets the sign of that bin by chance and moves every pixel by
+    2 * 0.3 * |X_bin| / (H W) ~ 1e-3.  The library computes this one transform in double, so the result matches the
+    reference's own phase_consistency output for that image to fp32 accuracy."""
+    from ddpm_image_restoration_amd.sampler import phase_consistency
+    g = golden("jpeg")
+    y = g["samp_y"]
+    mags = np.abs(np.fft.fft2(y.astype(np.float64))).reshape(y.shape[0], -1).min(axis=1)
+    assert mags[1] < 1e-6 and (np.delete(mags, 1) > 1e-3).all()          # the fixture really has the degenerate bin
+    x = g["samp_xt_in_40"]                                                # a noisy x_t of the same run
+    # the oracle's phase_consistency follows the reference (numpy's pocketfft == torch's CPU FFT kernel) -- checked against
+    # the reference's own pc_out in tests/test_oracle_golden.py
+    want = O.phase_consistency(x, y, 0.7)
+    got = phase_consistency(models(spec.ARCH_JPEG), tt(x), tt(y), alpha=0.7).cpu().numpy()
+    assert np.abs(got - want).reshape(y.shape[0], -1).max(axis=1).max() < 2e-5
 
 
 @pytest.mark.parametrize("name,arch", ARCHS)
@@ -238,6 +393,61 @@ def test_weight_blob_adoption_matches_direct_load(golden, synth_state):
         assert torch.equal(a, b)        # both modes are bit-reproducible (split-K partials are folded in a fixed order)
         assert torch.equal(a, root(tt(g["fwd32_x"]), tt(g["fwd32_t"]), tt(g["fwd32_cl"])))
         assert other.param_count() == spec.param_count(spec.ARCH_JPEG)
+
+
+@pytest.mark.parametrize("name,arch", [("webp", spec.ARCH_WEBP), ("avif", spec.ARCH_AVIF)])
+def test_builtin_host_codec_pool_equals_pillow_callback_in_the_loop(name, arch, models):
+    """codec == NULL for WebP / AVIF: the library's libwebp / libavif pool inside the two-lane loop gives exactly what the
+    callback into Pillow (the reference's own calls) gives -- with the phase fix (q10) and without (q50)."""
+    import torch
+    from ddpm_image_restoration_amd.sampler import SAMPLER_BY_ARCH
+    s = SAMPLER_BY_ARCH[arch](models(arch))
+    for q, size in ((10, 32), (50, 64)):
+        y = tt(O.compress(synth.synth_images(4, size, seed=60 + q), q, name))
+        a = s.sample(y, q, steps=6, seed=3, host_codec="pillow")
+        b = s.sample(y, q, steps=6, seed=3, host_codec="native")
+        assert torch.equal(a, b), (name, q)
+
+
+def test_half_precision_checkpoints_load_exactly(golden, synth_state):
+    """ddpmir_load_tensor(dtype): a checkpoint stored in bf16 / fp16 crosses the C ABI in its storage type and is widened
+    exactly -- same outputs as loading the float32 tensors holding the same (rounded) values."""
+    import torch
+    from ddpm_image_restoration_amd.model import WebPDiffusionModel
+    g = golden("webp")
+    dev = torch.device("cuda", 0)
+    for half in (torch.bfloat16, torch.float16):
+        sd_h = {k: torch.from_numpy(v).to(half) for k, v in synth_state(spec.ARCH_WEBP).items()}
+        a = WebPDiffusionModel(device=dev); a.load_state_dict(sd_h)
+        b = WebPDiffusionModel(device=dev); b.load_state_dict({k: v.float() for k, v in sd_h.items()})
+        x, t, cl = tt(g["fwd32_x"]), tt(g["fwd32_t"]), tt(g["fwd32_cl"])
+        assert torch.equal(a(x, t, cl), b(x, t, cl)), half
+
+
+def test_model_object_guards(tmp_path, synth_state):
+    """finalize twice, a packed blob of another configuration, and .to() another GPU index are errors, not garbage."""
+    import torch
+    from ddpm_image_restoration_amd.model import JPEGDiffusionModel, WebPDiffusionModel
+    dev = torch.device("cuda", 0)
+    m = JPEGDiffusionModel(device=dev, dtype="bf16")
+    blob = torch.empty(m.weight_blob_bytes(), dtype=torch.uint8, device=dev)
+    for k, v in synth_state(spec.ARCH_JPEG).items():
+        m._load_one(k, v)
+    m.finalize(blob=blob, fill=True)
+    with pytest.raises(RuntimeError, match="already finalized"):
+        m.finalize(blob=blob, fill=False)
+    m.save_packed(str(tmp_path / "jpeg_bf16.npy"))
+    JPEGDiffusionModel(device=dev, dtype="bf16").load_packed(str(tmp_path / "jpeg_bf16.npy"))        # same configuration: fine
+    for other in (JPEGDiffusionModel(device=dev, dtype="f32"), JPEGDiffusionModel(device=dev, dtype="bf16", attn_levels="bottleneck")):
+        with pytest.raises(RuntimeError, match="does not match"):
+            other.load_packed(str(tmp_path / "jpeg_bf16.npy"))
+    with pytest.raises(RuntimeError, match="does not match"):        # WebP and JPEG blobs have the same byte count
+        WebPDiffusionModel(device=dev, dtype="bf16").load_packed(str(tmp_path / "jpeg_bf16.npy"))
+    assert m.to("cuda") is m and m.to(torch.device("cuda", 0)) is m
+    with pytest.raises(RuntimeError, match="lives on"):
+        m.to("cuda:1")
+    with pytest.raises(RuntimeError):
+        m.to("cpu")
 
 
 def test_checkpoint_converter_roundtrip(tmp_path, golden, synth_state):

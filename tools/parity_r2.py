@@ -82,6 +82,22 @@ for arch in (0, 1, 2):
                 print(nm, f"R={R} q={qq} steps={st}: compressed {pc.mean():.4f} dB, restored f32 {p32.mean():.4f} bf16 {p16.mean():.4f}; "
                       f"mean diff {d.mean():+.4f} dB, per-image |diff| max {np.abs(d).max():.4f}, pixels max {np.abs(r16 - r32).max():.3f} "
                       f"batch-PSNR f32 {harness.psnr(torch.from_numpy(r32), torch.from_numpy(x0)):.4f} bf16 {harness.psnr(torch.from_numpy(r16), torch.from_numpy(x0)):.4f}")
+    if "psnrN" in what and arch == 1:
+        import time
+        for R, nbatch, bs in ((32, 4, 256), (64, 2, 128)):
+            d_all, p_all = [], []
+            t0 = time.time()
+            for k in range(nbatch):
+                x0 = synth.synth_images(bs, R, seed=900 + 10 * R + k)
+                y = harness.COMPRESS[arch](torch.from_numpy(x0), 10).cuda()
+                st = harness.steps_for_quality(arch, 10)
+                r32 = SAMPLER_BY_ARCH[arch](m32).sample(y, 10, steps=st, seed=3, image_offset=k * bs).cpu().numpy()
+                r16 = SAMPLER_BY_ARCH[arch](m16).sample(y, 10, steps=st, seed=3, image_offset=k * bs).cpu().numpy()
+                p32, p16 = psnr_each(r32, x0), psnr_each(r16, x0)
+                d_all.append(p16 - p32); p_all.append(p32)
+            d = np.concatenate(d_all); p32 = np.concatenate(p_all)
+            print(nm, f"R={R} N={d.size}: restored f32 mean {p32.mean():.4f} dB; bf16-f32 mean {d.mean():+.5f} dB, std {d.std():.4f}, "
+                  f"|d| max {np.abs(d).max():.4f}, p99 {np.percentile(np.abs(d), 99):.4f}; wall {time.time() - t0:.1f} s", flush=True)
     del m32, m16
     torch.cuda.empty_cache()
 
