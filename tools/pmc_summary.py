@@ -1,6 +1,9 @@
 """Per-kernel HBM-side traffic of the bench workload from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
-usage: pmc_summary.py <fetch_dir> <write_dir> <n_forwards>.  FETCH_SIZE is doubled (gfx950 tallies 128-B requests
-at 64 B); both counters are in KiB.  Durations are the dispatch timestamps of the same (profiled) runs."""
+usage: pmc_summary.py <fetch_dir> <write_dir> <n_forwards> [--json FILE --key WORKLOAD_KEY --command "bench command"]
+FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B); both counters are in KiB.  Durations are the dispatch
+timestamps of the same (profiled) runs.  With --json the bytes per launch of the roofline kernel (the level-0 attention
+dispatches: the flash kernel launches with the largest grid) are merged into FILE under WORKLOAD_KEY -- that is what
+bench.py reports as roofline.traffic, with this file as its stated source."""
 import collections
 import csv
 import glob
@@ -22,13 +25,32 @@ def load(d, counter):
     return agg
 
 
+def roofline_kernel_bytes(d, counter):
+    """mean counter value (KiB) over the level-0 attention dispatches: flash kernel launches with the largest grid"""
+    import os
+    f = max(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "flash_bf16" in r["Kernel_Name"]]
+    if not rows:
+        return None, None, 0
+    gmax = max(int(r["Grid_Size"]) for r in rows)
+    sel = [r for r in rows if int(r["Grid_Size"]) == gmax]
+    name = sel[0]["Kernel_Name"].replace("void ", "").replace("ddpmir::(anonymous namespace)::", "").split("(")[0]
+    return sum(float(r["Counter_Value"]) for r in sel) / len(sel), name, len(sel)
+
+
 fe, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 n = int(sys.argv[3])
+if n <= 0:   # one image-layout kernel per U-Net forward
+    n = max(1, next((v[0] for k, v in fe.items() if "nchw3_to_nhwc4" in k), 1))
 print(f"{'kernel':58s} {'calls/fwd':>9s} {'ms/fwd':>8s} {'read GB':>8s} {'write GB':>8s} {'GB/s':>7s}   (per forward; read = FETCH_SIZE x2)")
 tot = [0.0, 0.0, 0.0]
+setup = None
 for k in sorted(fe, key=lambda k: -fe[k][2]):
     c, f_kib, ms = fe[k]
     w_kib = wr.get(k, [0, 0.0, 0.0])[1]
+    if "fillBufferAligned" in k:   # hipMemset of the workspace arena and of the weight blob: once per context, not per forward
+        setup = (c, w_kib * 1024 / 1e9, ms)
+        continue
     rd, wrb = 2 * f_kib * 1024 / 1e9 / n, w_kib * 1024 / 1e9 / n
     ms /= n
     tot[0] += rd; tot[1] += wrb; tot[2] += ms
@@ -36,3 +58,26 @@ for k in sorted(fe, key=lambda k: -fe[k][2]):
         continue
     print(f"{k[:58]:58s} {c / n:9.1f} {ms:8.3f} {rd:8.3f} {wrb:8.3f} {(rd + wrb) / (ms / 1e3):7.0f}")
 print(f"{'all kernels':58s} {'':9s} {tot[2]:8.3f} {tot[0]:8.3f} {tot[1]:8.3f} {(tot[0] + tot[1]) / (tot[2] / 1e3):7.0f}")
+if setup:
+    print(f"(one-time setup, not in the table: {setup[0]} hipMemset launches clearing the workspace arena / weight blob, {setup[1]:.2f} GB, {setup[2]:.2f} ms)")
+
+if "--json" in sys.argv:
+    import json, os, subprocess
+    out = sys.argv[sys.argv.index("--json") + 1]
+    key = sys.argv[sys.argv.index("--key") + 1]
+    cmd = sys.argv[sys.argv.index("--command") + 1] if "--command" in sys.argv else None
+    f_kib, name, nl = roofline_kernel_bytes(sys.argv[1], "FETCH_SIZE")
+    w_kib, _, _ = roofline_kernel_bytes(sys.argv[2], "WRITE_SIZE")
+    doc = json.load(open(out)) if os.path.exists(out) else {"workloads": {}}
+    try:
+        doc["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or doc.get("commit")
+    except Exception:
+        pass
+    if f_kib is not None and w_kib is not None:
+        doc["workloads"][key] = {"roofline_kernel": name, "launches_averaged": nl,
+                                 "fetch_bytes_per_launch": 2 * f_kib * 1024, "write_bytes_per_launch": w_kib * 1024,
+                                 "roofline_kernel_bytes_per_launch": 2 * f_kib * 1024 + w_kib * 1024,
+                                 "all_kernels_read_GB_per_forward": tot[0], "all_kernels_write_GB_per_forward": tot[1],
+                                 "command": cmd, "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes"}
+        json.dump(doc, open(out, "w"), indent=1)
+        print(f"merged {key} into {out}: {doc['workloads'][key]['roofline_kernel_bytes_per_launch'] / 1e9:.3f} GB per level-0 launch")

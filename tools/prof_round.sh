@@ -1,8 +1,26 @@
-# Refreshes the committed profile evidence: default bench line + rocprofv3 kernel stats of the same command.
+# Refreshes the committed profile evidence of one bench workload at HEAD:
+#   bash tools/prof_round.sh <tag> <traffic key> [bench.py args ...]
+#   e.g.  bash tools/prof_round.sh r02_jpeg jpeg_bf16_256_B16_all
+#         bash tools/prof_round.sh r02_avif avif_bf16_256_B16_all --arch avif --T 250
+# writes under gpurun_out/ (copy into profiles/ afterwards):
+#   <tag>_bench.json                 the bench line (un-profiled run)
+#   <tag>_kernel_stats.csv           rocprofv3 --kernel-trace --stats of the same command
+#   <tag>_per_forward_summary.txt    per-kernel ms per forward + the level-0 attention launches
+#   <tag>_hbm_traffic.txt            per-kernel HBM bytes from two PMC passes (FETCH_SIZE x2, WRITE_SIZE)
+#   r02_traffic.json                 bytes per launch of the roofline kernel -> bench.py's roofline.traffic
+tag=$1; key=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-python3 bench.py > gpurun_out/r01_bench_bf16_default.json 2> gpurun_out/r01_bench.err || exit 1
-rm -rf gpurun_out/prof_r01
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01 -- python3 bench.py > gpurun_out/prof_r01.log 2>&1 || exit 1
-python3 tools/prof_summary.py gpurun_out/prof_r01 6 > gpurun_out/r01_bench_bf16_per_forward_summary.txt 2>&1
-cp "$(ls -t gpurun_out/prof_r01/*/*kernel_stats.csv | head -1)" gpurun_out/r01_bench_bf16_kernel_stats.csv
+mkdir -p gpurun_out
+[ -f profiles/r02_traffic.json ] && [ ! -f gpurun_out/r02_traffic.json ] && cp profiles/r02_traffic.json gpurun_out/r02_traffic.json
+python3 bench.py "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
+rm -rf gpurun_out/prof_${tag} gpurun_out/pmcf_${tag} gpurun_out/pmcw_${tag}
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/prof_${tag}.log 2>&1 || exit 1
+python3 tools/prof_summary.py gpurun_out/prof_${tag} 0 > gpurun_out/${tag}_per_forward_summary.txt 2>&1
+cp "$(ls -t gpurun_out/prof_${tag}/*/*kernel_stats.csv | head -1)" gpurun_out/${tag}_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcf_${tag} -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/pmcf_${tag}.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcw_${tag} -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/pmcw_${tag}.log 2>&1 || exit 1
+python3 tools/pmc_summary.py gpurun_out/pmcf_${tag} gpurun_out/pmcw_${tag} 0 --json gpurun_out/r02_traffic.json --key ${key} \
+        --command "python3 bench.py --steps 2 --warmup 1 $*" > gpurun_out/${tag}_hbm_traffic.txt 2>&1
+rm -rf gpurun_out/prof_${tag} gpurun_out/pmcf_${tag} gpurun_out/pmcw_${tag}
+tail -3 gpurun_out/${tag}_per_forward_summary.txt
