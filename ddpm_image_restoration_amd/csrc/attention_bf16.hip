@@ -130,28 +130,7 @@ constexpr float RESCALE_THR = 20.0f;   // log2 units
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// p = exp2(s - m) as the bf16 B operand of the PV MFMA: 16 fp32 registers -> 8 packed registers.
-// PK = 0: v_cvt_pk_bf16_f32 (round to nearest even).  PK = 1: v_perm_b32 taking the upper halves of two registers
-// (truncation).  Truncated p enter numerator (PV) and denominator (the ones row of V^T) alike, so the systematic part of
-// the truncation error cancels in O = PV / l and the random part has the same variance as round-to-nearest; only valid
-// where the denominator is formed from the SAME packed p (head_dim <= 16: ones row).
-template <int PK>
-__device__ __forceinline__ void pack_p(const f32x16& s, bf16x8 (&pb)[2]) {
-  if constexpr (PK == 1) {
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    u32x4 w[2];
-#pragma unroll
-    for (int r = 0; r < 16; r += 2)
-      w[r >> 3][(r & 7) >> 1] = __builtin_amdgcn_perm(__float_as_uint(s[r + 1]), __float_as_uint(s[r]), 0x07060302u);
-    pb[0] = __builtin_bit_cast(bf16x8, w[0]);
-    pb[1] = __builtin_bit_cast(bf16x8, w[1]);
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (__bf16)s[r];
-  }
-}
-
-template <int D, int QS, int TS, int WPS = 0, int DMA = 1, int DEN = 0, int PK = 0>
+template <int D, int QS, int TS, int WPS = 0, int DMA = 1, int DEN = 0>
 __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
                                                   const float* __restrict__ Kmax, float* __restrict__ out, int ldo,
                                                   int N, int NT, int heads, int nqb, int npairs,
@@ -312,8 +291,7 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
           for (int c = 0; c < G::KC; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[u][c], s, 0, 0, 0);
           bf16x8 pb[2];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
-          pack_p<PK>(s, pb);
+          for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r]); pb[r >> 3][r & 7] = (__bf16)s[r]; }
           if (!G::ONES && DEN) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) { lacc[u].x += s[r]; lacc[u].y += s[r + 1]; }
@@ -398,10 +376,10 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          s[r] = __builtin_amdgcn_exp2f(s[r]);
-          ps += s[r];
+          float p = __builtin_amdgcn_exp2f(s[r]);
+          pb[r >> 3][r & 7] = (__bf16)p;
+          ps += p;
         }
-        pack_p<PK>(s, pb);
         if (!G::ONES && DEN) lacc[u].x += ps;
         else if (!G::ONES) {
           osum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[0], osum[u], 0, 0, 0);
@@ -456,7 +434,7 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
   }
 }
 
-template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT, int WPS = 0, int DMA = 1, int DEN = 0, int PK = 0>
+template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT, int WPS = 0, int DMA = 1, int DEN = 0>
 void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* ws, hipStream_t s,
                void* out16) {
   using G = AttnGeom<D>;
@@ -473,11 +451,10 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
   const int nqb = (N + 128 * QS - 1) / (128 * QS);
   static PerDeviceOnce attr;
   attr.run([] {
-    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16<D, QS, TS, WPS, DMA, DEN, PK>),
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16<D, QS, TS, WPS, DMA, DEN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SG::STAGE_BYTES + 2 * TS * 4));
   });
-  static_assert(PK == 0 || AttnGeom<D>::ONES, "truncating pack needs the ones-row denominator");
-  hipLaunchKernelGGL((flash_bf16<D, QS, TS, WPS, DMA, DEN, PK>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
+  hipLaunchKernelGGL((flash_bf16<D, QS, TS, WPS, DMA, DEN>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
                      out, ldo, N, NT, heads, nqb, BH, reinterpret_cast<__bf16*>(out16));
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
@@ -572,8 +549,6 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
       case 9: run_flash<16, 1, 16, 0, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 10: run_flash<16, 2, 8, 3, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 11: run_flash<16, 2, 4, 3, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 12: run_flash<16, 2, 16, 0, 1, 0, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;   // v_perm packing
-      case 13: run_flash<16, 2, 16, 3, 1, 0, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;   // + 3 waves/SIMD
       default: break;
     }
   }
