@@ -28,7 +28,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md (fp8 mode: the roofline kernel -- attention -- stays bf16)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp8": 2500.0}
 NOISE_COEFF = {"jpeg": 0.2, "webp": 0.2, "avif": 0.15}
 PHASE = {"jpeg": (20, 5, 0.7), "webp": (15, 5, 0.7), "avif": (30, 3, 0.8)}     # quality threshold, period, alpha
 
@@ -93,7 +94,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--quality", type=int, default=10)
     ap.add_argument("--attn", choices=["all", "bottleneck"], default="all")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "fp8"], default="bf16", help="fp8 = bf16 + e4m3 operands in the deep 3x3 convs (configs[4])")
     ap.add_argument("--codec", choices=["host", "device"], default=None, help="JPEG only: device (default) or host Pillow codec")
     ap.add_argument("--host-codec", choices=["native", "pillow"], default="native", help="WebP / AVIF: library pool or Pillow callback")
     ap.add_argument("--graph", type=int, default=0, help="1 = replay the timestep as captured hipGraphs")
@@ -197,7 +198,9 @@ def main():
                                       else "variant of BASELINE configs", args.arch.upper(), R, R, B, T, args.arch.upper(), q),
                        "global_batch": n_total, "image": R, "T": T, "quality": q, "attn_levels": args.attn,
                        "codec": codec_txt, "timestep_launch": "captured hipGraphs" if args.graph else "eager",
-                       "arithmetic": "bf16 matrix-core operands, fp32 accumulation/softmax/GroupNorm statistics, fp32 residual stream" if args.dtype == "bf16" else "fp32 matrix cores",
+                       "arithmetic": {"bf16": "bf16 matrix-core operands, fp32 accumulation/softmax/GroupNorm statistics, fp32 residual stream",
+                                      "fp8": "as bf16, with OCP e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4) in the 3x3 convs with >= 256 channels",
+                                      "f32": "fp32 matrix cores"}[args.dtype],
                        "parallelism": f"dp{env.world} (independent image shards, no collective in the loop)"},
             "distributed": {"backend": env.backend if env.world > 1 else None, "world_size": env.world,
                             "weight_blob_bytes": model.weight_blob_bytes(),

@@ -22,6 +22,7 @@
 //  a linear 1 KiB wave read (conflict-free).  Workgroups of one (batch, head) are placed on one XCD so the
 //  4 MiB of K/V they all re-read stay in that XCD's L2.
 #include <cstdlib>
+#include <stdexcept>
 
 #include "kernels.h"
 
@@ -517,6 +518,7 @@ size_t attention_bf16_workspace(int B, int N, int C, int heads) {
 
 void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* workspace,
                            hipStream_t s, void* out16) {
+  if (!workspace || (!out && !out16)) throw std::logic_error("attention_bf16: workspace / output pointer missing");
 #ifdef DDPMIR_EXPERIMENTS   // tile-shape A/B instantiations (tools/attn_ab*.py); the shipped library has one kernel per head_dim
   const int var = exp_value("DDPMIR_ATTN_VARIANT");
   if (C / heads == 32 && var >= 20) {   // head_dim 32 experiments

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -78,6 +80,30 @@ struct PerDeviceOnce {
     if (!(done & bit)) { f(); done |= bit; }
   }
 };
+
+// float -> OCP e4m3fn byte (1-4-3, bias 7, max finite 448, no infinities), round to nearest even, saturating: the host-side
+// twin of v_cvt_pk_fp8_f32 on gfx950, used to pack fp8 weights
+static inline unsigned char f32_to_e4m3(float f) {
+  unsigned int u;
+  memcpy(&u, &f, 4);
+  const unsigned char sign = (unsigned char)((u >> 24) & 0x80u);
+  const float a = fabsf(f);
+  if (a != a) return (unsigned char)(sign | 0x7F);
+  if (a >= 448.f) return (unsigned char)(sign | 0x7E);
+  int e;
+  (void)frexpf(a, &e);                       // a = m * 2^e, m in [0.5, 1)  ->  a = 1.x * 2^(e-1)
+  int E = e - 1;
+  if (a == 0.f) return sign;
+  if (E < -6) {                              // subnormal range: multiples of 2^-9
+    const int r = (int)nearbyintf(a * 512.f);
+    return (unsigned char)(sign | (r >= 8 ? 0x08 : r));
+  }
+  int r = (int)nearbyintf(a / ldexpf(1.f, E - 3));   // mantissa with the hidden bit, 8 .. 16
+  if (r == 16) { r = 8; E += 1; }
+  unsigned bits = (unsigned)(((E + 7) << 3) | (r - 8));
+  if (bits > 0x7E) bits = 0x7E;
+  return (unsigned char)(sign | bits);
+}
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

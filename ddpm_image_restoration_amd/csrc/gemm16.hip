@@ -37,17 +37,38 @@ namespace {
 
 constexpr int BM = 128;
 
+// four fp32 -> four OCP e4m3 bytes (round to nearest even, clamped to the finite range +-448)
+__device__ __forceinline__ unsigned pack_e4m3x4(float4 v) {
+  const float lim = 448.f;
+  v.x = fminf(fmaxf(v.x, -lim), lim); v.y = fminf(fmaxf(v.y, -lim), lim);
+  v.z = fminf(fmaxf(v.z, -lim), lim); v.w = fminf(fmaxf(v.w, -lim), lim);
+  int r = 0;
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(v.x, v.y, r, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(v.z, v.w, r, true);
+  return (unsigned)r;
+}
+
 // BK = K elements per stage (64 or 32).  BK = 32 keeps the workgroup at 32 KiB of ring so four of them share one CU:
 // one workgroup's barrier waits, LDS-read latency and epilogue overlap the MFMAs of the others.
 // STAGES = 2 (double buffering, one stage in flight per workgroup): measured better than a 3-stage ring with two stages
 // in flight because the smaller footprint admits a fourth workgroup per CU at BK = 32 (32 KiB ring, 36 KiB epilogue
 // tile) and a second one at BK = 64 -- occupancy hides the load latency better than a deeper ring does (3x3 convs of
 // levels 1-3: -3 %, levels 4-5: -11 %, level-0 1x1: -25 %).
-template <int NT, int BK, int STAGES>
-__global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
+//
+// F8 = 1: both operands are OCP e4m3 bytes (same LDS geometry: a row of BK*2 bytes now holds 2*BK K elements, a 16-byte
+// chunk 16 of them) and the contraction runs on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales: twice the bf16
+// MFMA rate and half the operand bytes per MAC.  The per-tensor weight scale is undone on the accumulators (acc_scale).
+// The 128-column bf16 tile at BK = 32 is compiled for four waves per SIMD (<= 128 VGPRs; the compiler spills two registers
+// outside the K loop): its 36 KiB LDS footprint already allows four workgroups per CU, 133 VGPRs only three.  A/B on one
+// device (tools/lib_ab_bench.py): forward minus level-0 attention 15.26 -> 14.93 ms, all GEMMs of a forward 6.98 -> 6.85 ms.
+template <int NT, int BK, int STAGES, int F8 = 0>
+__global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void gemm16_kernel(const IGemm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ROWB = BK * 2;                         // bytes per LDS row
   constexpr int CPR = BK / 8;                          // 16-byte chunks per row
+  constexpr int EB = F8 ? 1 : 2;                       // bytes per operand element
+  constexpr int EPC = 16 / EB;                         // K elements per 16-byte chunk
+  constexpr int BKE = CPR * EPC;                       // K elements per stage
   constexpr int RSH = BK == 64 ? 1 : 2;                // rows per 256-byte bank row = 1 << RSH
   constexpr int BROWS = NT * 32 * CPR < 256 ? 256 / CPR : NT * 32;   // every thread issues >= 1 B piece
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BROWS * ROWB, STAGE = A_BYTES + B_BYTES;
@@ -68,14 +89,16 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
     if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
   }
   const int m0 = bx * BM, n0 = by * (NT * 32);
-  const int nck = (p.Cin + BK - 1) / BK;
+  const int nck = (p.Cin + BKE - 1) / BKE;
   const int nit_main = p.taps * nck;
-  const int nit_all = nit_main + (p.Cinb + BK - 1) / BK;
+  const int nit_all = nit_main + (F8 ? 0 : (p.Cinb + BK - 1) / BK);
   const int nsplit = gridDim.z, sk = blockIdx.z;
   const int it0 = (int)((long long)nit_all * sk / nsplit), it1 = (int)((long long)nit_all * (sk + 1) / nsplit);
   const int nit = (GEMM_DBG(p) & 16) ? 0 : it1 - it0;
   const __bf16* A16 = reinterpret_cast<const __bf16*>(p.A16);
   const __bf16* W16 = reinterpret_cast<const __bf16*>(p.Wt16);
+  const unsigned char* A8 = reinterpret_cast<const unsigned char*>(p.A16);    // F8: the same fields carry e4m3 tensors
+  const unsigned char* W8 = reinterpret_cast<const unsigned char*>(p.Wt16);
   const __bf16* A16b = reinterpret_cast<const __bf16*>(p.A16b);
   const __bf16* W16b = reinterpret_cast<const __bf16*>(p.Wt16b);
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zero16) +
@@ -131,24 +154,28 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
     // channel chunk outer, tap inner: the nine taps of one chunk re-read the same few A cache lines back to back (L2 / TCP
     // hits).  Tap-major order streamed the whole channel depth between two uses of a line and re-fetched every tap through
     // the fabric (PMC: 1 096 MB fetched for a 134 MB operand at 256 -> 64, 128 x 128: 181 -> 159 us).
-    const int ck = it / p.taps, tap = it - ck * p.taps, c0 = ck * BK;
+    const int ck = it / p.taps, tap = it - ck * p.taps, c0 = ck * BKE;
     int dy = 0, dx = 0;
     if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
     const unsigned sbase = lds0 + (itl % STAGES) * STAGE;
     if (!(GEMM_DBG(p) & 1))
 #pragma unroll
     for (int j = 0; j < AL; ++j) {
-      const int c = c0 + 8 * a_chunk[j];
+      const int c = c0 + EPC * a_chunk[j];
       const bool ok = a_ok[j] && c < p.Cin && (unsigned)(a_y[j] + dy) < (unsigned)p.H && (unsigned)(a_x[j] + dx) < (unsigned)p.W;
-      const void* g = ok ? (const void*)(A16 + a_off[j] + (ptrdiff_t)(dy * p.W + dx) * p.lda16 + c) : (const void*)zero;
+      const void* g = !ok ? (const void*)zero
+                          : F8 ? (const void*)(A8 + a_off[j] + (ptrdiff_t)(dy * p.W + dx) * p.lda16 + c)
+                               : (const void*)(A16 + a_off[j] + (ptrdiff_t)(dy * p.W + dx) * p.lda16 + c);
       __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sbase + (j * 256 + wave * 64) * 16), 16, 0, 0);
     }
     if (!(GEMM_DBG(p) & 2))
 #pragma unroll
     for (int j = 0; j < BL; ++j) {
-      const int c = c0 + 8 * b_chunk[j];
+      const int c = c0 + EPC * b_chunk[j];
       const bool ok = b_n[j] < p.Cout && c < p.Cin;
-      const void* g = ok ? (const void*)(W16 + ((size_t)tap * p.Cout + b_n[j]) * p.Cin + c) : (const void*)zero;
+      const void* g = !ok ? (const void*)zero
+                          : F8 ? (const void*)(W8 + ((size_t)tap * p.Cout + b_n[j]) * p.Cin + c)
+                               : (const void*)(W16 + ((size_t)tap * p.Cout + b_n[j]) * p.Cin + c);
       __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sbase + A_BYTES + (j * 256 + wave * 64) * 16), 16, 0, 0);
     }
   };
@@ -175,6 +202,32 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
     __builtin_amdgcn_s_barrier();
     if (it + AHEAD < nit) issue(it + AHEAD);
     const unsigned char* st = smem + (it % STAGES) * STAGE;
+    if constexpr (F8) {
+      // one 32x32x64 MFMA per 64 K bytes of the row: lane half lh holds k = 32 lh .. 32 lh + 31 = chunks 2 lh, 2 lh + 1
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      typedef int i32x8 __attribute__((ext_vector_type(8)));
+      constexpr int KS8 = ROWB / 64;
+      i32x8 a8[KS8], b8[KS8][NT];
+#pragma unroll
+      for (int ks = 0; ks < KS8; ++ks) {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(st + arow * ROWB + (((4 * ks + 2 * lh) ^ a_key) << 4));
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(st + arow * ROWB + (((4 * ks + 2 * lh + 1) ^ a_key) << 4));
+        a8[ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const unsigned char* br = st + A_BYTES + (nt * 32 + lr) * ROWB;
+          const i32x4 blo = *reinterpret_cast<const i32x4*>(br + (((4 * ks + 2 * lh) ^ b_key) << 4));
+          const i32x4 bhi = *reinterpret_cast<const i32x4*>(br + (((4 * ks + 2 * lh + 1) ^ b_key) << 4));
+          b8[ks][nt] = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS8; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[ks], b8[ks][nt], acc[nt], 0, 0, 0, 0, 0, 0);
+      continue;
+    }
     // all operand fragments of the stage first (one LDS round trip), then the MFMAs back to back
     bf16x8 af[KS], bfr[KS][NT];
 #pragma unroll
@@ -190,6 +243,13 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
       for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bfr[ks][nt], acc[nt], 0, 0, 0);
   }
 
+  if constexpr (F8) {   // undo the per-tensor weight scale (a power of two)
+    const float sc = p.acc_scale;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] *= sc;
+  }
   // ------------------------------------------------------------------------------------------ epilogue
   if ((GEMM_DBG(p) & 8) && acc[0][0] != 12345.f) return;
   const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE || p.sel_C;
@@ -349,6 +409,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const IGemm p) {
         o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
         *reinterpret_cast<bf16x4*>(out16 + (size_t)m * p.ldo16 + no) = o;
       }
+      if (p.out8) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.out8) + (size_t)m * p.ldo8 + no) = pack_e4m3x4(v);
     }
     if (p.gn_sums) {
       // the wave's 32 rows lie in one image (HW % 32 == 0); fold rows (lanes L4 apart), then the lanes of one group
@@ -392,6 +453,7 @@ __global__ void splitk_reduce_k(const IGemm p, int nsplit, int64_t M, int HW) {
       o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
       *reinterpret_cast<bf16x4*>(out16 + (size_t)m * p.ldo16 + n) = o;
     }
+    if (p.out8) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.out8) + (size_t)m * p.ldo8 + n) = pack_e4m3x4(v);
   }
 }
 
@@ -399,7 +461,8 @@ __global__ void splitk_reduce_k(const IGemm p, int nsplit, int64_t M, int HW) {
 // (x*scale[b][c] + shift[b][c], then act); optionally also a raw bf16 copy (input of the 1x1 shortcut conv).
 __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C, int Cs, const float* __restrict__ scale,
                              const float* __restrict__ shift, int act, __bf16* __restrict__ out, int ld16,
-                             __bf16* __restrict__ raw, int ldraw, int64_t M, double* __restrict__ zero, int nzero) {
+                             __bf16* __restrict__ raw, int ldraw, int64_t M, double* __restrict__ zero, int nzero,
+                             unsigned char* __restrict__ out8, int ld8) {
   if (blockIdx.x == 0)
     for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0.0;
   const int C8 = (C + 7) / 8;
@@ -433,10 +496,16 @@ __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C
     for (int j = 0; j < 8; ++j) { o[j] = (__bf16)v[j]; q[j] = (__bf16)r[j]; }
     if (out) *reinterpret_cast<bf16x8*>(out + m * ld16 + c) = o;
     if (raw) *reinterpret_cast<bf16x8*>(raw + m * ldraw + c) = q;
+    if (out8) {   // e4m3 operand of an fp8 conv (C % 8 == 0 there)
+      uint2 w;
+      w.x = pack_e4m3x4(make_float4(v[0], v[1], v[2], v[3]));
+      w.y = pack_e4m3x4(make_float4(v[4], v[5], v[6], v[7]));
+      *reinterpret_cast<uint2*>(out8 + m * ld8 + c) = w;
+    }
   }
 }
 
-template <int NT, int BK, int STAGES>
+template <int NT, int BK, int STAGES, int F8 = 0>
 void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   constexpr int CPR = BK / 8;
   constexpr int BROWS = NT * 32 * CPR < 256 ? 256 / CPR : NT * 32;
@@ -446,13 +515,13 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   constexpr int LDS = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
   static PerDeviceOnce attr;
   attr.run([] {
-    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<NT, BK, STAGES>),
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<NT, BK, STAGES, F8>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   });
   const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
-  const int nit = p.taps * cdiv(p.Cin, BK) + cdiv(p.Cinb, BK);
+  const int nit = p.taps * cdiv(p.Cin, F8 ? 2 * BK : BK) + cdiv(p.Cinb, BK);
   int nsplit = 1;
-  const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && (p.out || p.out16) && !p.pk_q &&
+  const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && (p.out || p.out16 || p.out8) && !p.pk_q &&
                       !p.sel_C && !p.gn_sums && p.splitk_ws;
   if (linear && gx * gy < 256 && nit >= 8 * (64 / BK)) {
     nsplit = std::min(std::min(16, nit / (4 * (64 / BK))), cdiv(512, gx * gy));
@@ -462,7 +531,7 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   IGemm q = p;
   q.nmajor = gx * gy < 256;                             // few M tiles: the weight stream is what to keep inside one L2
   const dim3 grid = q.nmajor ? dim3(gy, gx, nsplit) : dim3(gx, gy, nsplit);
-  hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES>), grid, dim3(256), LDS, stream, q);
+  hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES, F8>), grid, dim3(256), LDS, stream, q);
   if (nsplit > 1)
     hipLaunchKernelGGL(splitk_reduce_k, dim3((unsigned)std::min<int64_t>(cdiv64(M * (p.Cout / 4), 256), 2048)), dim3(256), 0, stream,
                        p, nsplit, M, p.H * p.W);
@@ -479,6 +548,14 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
   const bool no_longk = exp_switch("DDPMIR_GEMM_NO_LONGK");   // A/B switch
   const bool longk = !no_longk && p.taps == 9 && (NT <= 2 || ktot >= 2048);
   const bool bk64 = (GEMM_DBG(p) & 32) ? true : (GEMM_DBG(p) & 64) ? false : (tiles < 256 || longk);
+  if (p.f8) {   // fp8 operands: the deep 3x3 convs only (wide N tile); BK = 64 bytes-pairs = 128 K elements per stage
+    if constexpr (NT == 4) {
+      if (bk64) launch_nt<4, 64, 2, 1>(p, M, stream);
+      else launch_nt<4, 32, 2, 1>(p, M, stream);
+      return;
+    }
+    throw std::runtime_error("gemm16: fp8 operands need Cout > 64");
+  }
   if (bk64) launch_nt<NT, 64, 2>(p, M, stream);
   else launch_nt<NT, 32, 2>(p, M, stream);
 }
@@ -494,8 +571,9 @@ bool gemm16_can_fuse_gn(const IGemm& p, int groups) {
 }
 
 bool gemm16_supported(const IGemm& p) {
-  return p.A16 && p.Wt16 && p.zero16 && (p.Cin % 8) == 0 && (p.lda16 % 8) == 0 && (p.Cout % 4) == 0 &&
-         p.store == STORE_NHWC && p.pro_mask == MASK_NONE && !p.scale && p.pro_act == ACT_NONE;
+  const int al = p.f8 ? 16 : 8;       // a 16-byte chunk holds 16 e4m3 or 8 bf16 K elements
+  return p.A16 && p.Wt16 && p.zero16 && (p.Cin % al) == 0 && (p.lda16 % al) == 0 && (p.Cout % 4) == 0 &&
+         p.store == STORE_NHWC && p.pro_mask == MASK_NONE && !p.scale && p.pro_act == ACT_NONE && !(p.f8 && (p.Cinb || p.pk_q));
 }
 
 void launch_gemm16(const IGemm& p, hipStream_t stream) {
@@ -520,13 +598,14 @@ void launch_gemm16(const IGemm& p, hipStream_t stream) {
 }
 
 void launch_gn_apply16(const float* x, int ldx, int B, int HW, int C, const float* scale, const float* shift, int act,
-                       void* out16, int ld16, void* raw16, int ldraw, hipStream_t s, double* zero, int nzero) {
+                       void* out16, int ld16, void* raw16, int ldraw, hipStream_t s, double* zero, int nzero, void* out8, int ld8) {
   const int64_t M = (int64_t)B * HW;
   const int64_t total = M * ((C + 7) / 8);
   int64_t g = (total + 255) / 256;
   g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
   hipLaunchKernelGGL(gn_apply16_k, dim3((unsigned)g), dim3(256), 0, s, x, ldx, HW, C, round_up(C, 4), scale, shift, act,
-                     reinterpret_cast<__bf16*>(out16), ld16, reinterpret_cast<__bf16*>(raw16), ldraw, M, zero, nzero);
+                     reinterpret_cast<__bf16*>(out16), ld16, reinterpret_cast<__bf16*>(raw16), ldraw, M, zero, nzero,
+                     reinterpret_cast<unsigned char*>(out8), ld8);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

@@ -56,6 +56,9 @@ struct IGemm {
   // split-K partial sums [nsplit][M][Cout] fp32 (gemm16.hip): written by the splits, folded in fixed order by a second
   // kernel together with bias / time bias / residual / bf16 copy -> bf16 mode is bit-reproducible (no float atomics)
   float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;
+  // fp8 operands (gemm16.hip, F8): A16 / Wt16 then point to OCP e4m3 tensors (lda16 / Cin in elements = bytes), acc_scale
+  // undoes the per-tensor weight scale; out8 / ldo8: optional e4m3 copy of the epilogue result (operand of the next fp8 conv)
+  int f8 = 0; float acc_scale = 1.f; void* out8 = nullptr; int ldo8 = 0;
   int nmajor = 0;   // set by the launcher: blockIdx.x is the N tile (weight-bound shapes), see gemm16.hip
   int dbg = 0;   // timing experiments only: 1 skip A loads, 2 skip B loads, 4 skip MFMA, 8 skip stores, 16 skip LDS writes
 };
@@ -69,7 +72,8 @@ void launch_gn_from_sums(const double* sums, int B, int HW, int C, int G, const 
 // fp32 -> bf16 with GroupNorm affine + activation applied once for the consuming conv; optional raw bf16 copy
 // (zero/nzero: optionally clears a small fp64 accumulator, e.g. IGemm::gn_sums of the GEMM that consumes this operand)
 void launch_gn_apply16(const float* x, int ldx, int B, int HW, int C, const float* scale, const float* shift, int act,
-                       void* out16, int ld16, void* raw16, int ldraw, hipStream_t s, double* zero = nullptr, int nzero = 0);
+                       void* out16, int ld16, void* raw16, int ldraw, hipStream_t s, double* zero = nullptr, int nzero = 0,
+                       void* out8 = nullptr, int ld8 = 0);
 
 // ------------------------------------------------------------------------------------------------ attention
 // softmax(Q K^T / sqrt(d)) V per (batch, head); qkv is [B][N][3C] (q | k | v, heads contiguous in C),

@@ -38,6 +38,9 @@ struct ConvW {          // packed [taps][Cout][CinP] + bias
   void* w16 = nullptr;  // bf16 copy (DDPMIR_BF16 contexts)
   int cout = 0, cin = 0, cinp = 0, taps = 1;
   int cin16 = 0, cout16 = 0;   // strides of the bf16 copy: cinp/cout, or (Cin to 8, Cout to 4) for the DMA GEMM
+  // DDPMIR_FP8 contexts, 3x3 convs with >= 256 input and output channels: e4m3 copy [tap][cout16][cin16] of w * 2^k
+  // (k = the largest power of two that keeps max|w| * 2^k <= 448) and, in the blob, 2^-k for the epilogue
+  void* w8 = nullptr; float* w8_inv_dev = nullptr; float w8_inv = 1.f;
 };
 
 struct AvifTransformW {
@@ -140,6 +143,7 @@ class Context {
     float *xt = nullptr, *avg = nullptr, *col = nullptr, *edge = nullptr, *pool = nullptr, *pool8 = nullptr, *pg1 = nullptr, *pg2 = nullptr;
     unsigned char* attn_ws = nullptr;
     // bf16 operand tensors of the DMA-streamed GEMM path (dtype = bf16, DCT families)
+    unsigned char *a8 = nullptr, *S8 = nullptr;      // e4m3 operand tensors of the fp8 convs (DDPMIR_FP8)
     unsigned short *a16 = nullptr, *x16 = nullptr, *hB16 = nullptr, *att16 = nullptr, *xdl16 = nullptr, *xdh16 = nullptr,
                    *hid16 = nullptr, *S16 = nullptr;
     unsigned char* zero16 = nullptr;
@@ -170,7 +174,8 @@ class Context {
   void run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
   void run_block16(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
   void conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override = nullptr);
-  bool use_gemm16() const { return cfg.dtype == DDPMIR_BF16; }
+  bool use_gemm16() const { return cfg.dtype == DDPMIR_BF16 || cfg.dtype == DDPMIR_FP8; }
+  void conv8(const ConvW& cw, IGemm p, hipStream_t s);   // e4m3 operands (p.A16 = e4m3 tensor)
   void freq_dct(const BlockW& bw, int H, int W, hipStream_t s);
   void freq_avif(const BlockW& bw, int H, int W, hipStream_t s);
   void avif_transform(const AvifTransformW& at, const float* x, int ldx, int C, int H, int W, float* T, float* tmp,

@@ -40,7 +40,8 @@ ArchConsts consts_for(int arch) {
 }  // namespace
 
 Context::Context(const ddpmir_config& c) : cfg(c), k(consts_for(c.arch)) {
-  if (cfg.dtype != DDPMIR_F32 && cfg.dtype != DDPMIR_BF16) throw std::runtime_error("dtype must be DDPMIR_F32 or DDPMIR_BF16");
+  if (cfg.dtype != DDPMIR_F32 && cfg.dtype != DDPMIR_BF16 && cfg.dtype != DDPMIR_FP8)
+    throw std::runtime_error("dtype must be DDPMIR_F32, DDPMIR_BF16 or DDPMIR_FP8");
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
   DDPMIR_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   DDPMIR_HIP_CHECK(hipEventCreate(&ev0_));
@@ -93,7 +94,10 @@ void Context::put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name
   const size_t n = (size_t)cw.taps * cout * cw.cinp, n16 = (size_t)cw.taps * cw.cout16 * cw.cin16;
   cw.w = a.take<float>(n);
   cw.b = a.take<float>(cw.cout16);
-  cw.w16 = cfg.dtype == DDPMIR_BF16 ? a.take<unsigned short>(n16) : nullptr;
+  cw.w16 = use_gemm16() ? a.take<unsigned short>(n16) : nullptr;
+  const bool f8 = cfg.dtype == DDPMIR_FP8 && ksz == 3 && cin >= 256 && cout >= 256 && (cin % 16) == 0;
+  cw.w8 = f8 ? a.take<unsigned char>(n16) : nullptr;
+  cw.w8_inv_dev = f8 ? a.take<float>(1) : nullptr;
   n_params_ += (int64_t)cout * cin * cw.taps + cout;
   if (!upload) return;
   auto iw = host_.find(name + ".weight");
@@ -119,6 +123,19 @@ void Context::put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name
           p16[((size_t)t * cw.cout16 + o) * cw.cin16 + c] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
         }
     DDPMIR_HIP_CHECK(hipMemcpy(cw.w16, p16.data(), n16 * 2, hipMemcpyHostToDevice));
+  }
+  if (cw.w8) {   // e4m3 copy with a per-tensor power-of-two scale that uses the format's range (|w| <= 448 after scaling)
+    float amax = 0.f;
+    for (float v : packed) amax = std::max(amax, std::fabs(v));
+    const int kexp = amax > 0.f ? (int)std::floor(std::log2(448.0 / (double)amax)) : 0;
+    const float sw = std::ldexp(1.0f, kexp), inv = std::ldexp(1.0f, -kexp);
+    std::vector<unsigned char> p8(n16, 0);
+    for (int t = 0; t < cw.taps; ++t)
+      for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c)
+          p8[((size_t)t * cw.cout16 + o) * cw.cin16 + c] = f32_to_e4m3(packed[((size_t)t * cout + o) * cw.cinp + c] * sw);
+    DDPMIR_HIP_CHECK(hipMemcpy(cw.w8, p8.data(), n16, hipMemcpyHostToDevice));
+    DDPMIR_HIP_CHECK(hipMemcpy(cw.w8_inv_dev, &inv, 4, hipMemcpyHostToDevice));
   }
   std::vector<float> bias(cw.cout16, 0.f);
   std::memcpy(bias.data(), ib->second.data.data(), cout * sizeof(float));
@@ -291,6 +308,10 @@ void Context::finalize_weights(void* dev_blob, int fill) {
   if (fill) DDPMIR_HIP_CHECK(hipMemset(wblob_, 0, bytes));
   layout_weights(a, fill != 0);
   DDPMIR_HIP_CHECK(hipDeviceSynchronize());
+  if (cfg.dtype == DDPMIR_FP8)   // the fp8 weight scales travel inside the blob (adopted blobs carry them too)
+    for (auto& b : blocks_)
+      for (ConvW* cw : {&b.conv1, &b.conv2, &b.conv_out, &b.ep0, &b.ep2})
+        if (cw->w8) DDPMIR_HIP_CHECK(hipMemcpy(&cw->w8_inv, cw->w8_inv_dev, 4, hipMemcpyDeviceToHost));
   host_.clear();
   finalized_ = true;
 }
@@ -323,7 +344,7 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
     p.pool8 = a.take<float>((size_t)B * 64 * 1024);
     p.pg2 = a.take<float>((size_t)B * 85 * 1024);   // the four pooled gate maps (1 + 4 + 16 + 64 positions) back to back
   }
-  if (cfg.dtype == DDPMIR_BF16) {
+  if (use_gemm16()) {   // bf16 attention operand images (bf16 and fp8 modes)
     size_t ws = 0;
     for (auto& d : kBlocks)
       if (d.level >= cfg.attn_min_level && attention_bf16_supported((int)hw(d.level), d.cout, k.heads))
@@ -336,6 +357,12 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
     p.a16 = a.take<unsigned short>(ma); p.x16 = a.take<unsigned short>(ma);
     p.hB16 = a.take<unsigned short>(mc); p.att16 = a.take<unsigned short>(mc); p.xdl16 = a.take<unsigned short>(mc);
     p.xdh16 = a.take<unsigned short>(mc); p.hid16 = a.take<unsigned short>(mc); p.S16 = a.take<unsigned short>(mc);
+    if (cfg.dtype == DDPMIR_FP8) {
+      size_t m8 = 0;   // largest e4m3 operand: pixels * channels over the blocks that have fp8 convs (C >= 256: levels >= 2)
+      for (auto& d : kBlocks)
+        if (d.cout >= 256) m8 = std::max(m8, (size_t)B * hw(d.level) * (size_t)std::max(d.cin, d.cout));
+      p.a8 = a.take<unsigned char>(m8 + 16); p.S8 = a.take<unsigned char>(m8 + 16);
+    }
     p.zero16 = a.take<unsigned char>(GEMM16_ZERO_BYTES);
     p.splitk_ws = a.take<float>(GEMM16_SPLITK_WS_BYTES / sizeof(float));
   }
@@ -581,6 +608,14 @@ void Context::conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_
   else throw std::logic_error("conv16: operand layout not supported by the DMA GEMM");
 }
 
+void Context::conv8(const ConvW& cw, IGemm p, hipStream_t s) {
+  p.Wt = nullptr; p.Wt16 = cw.w8; p.bias = cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
+  p.f8 = 1; p.acc_scale = cw.w8_inv;
+  p.zero16 = plan_.zero16; p.splitk_ws = plan_.splitk_ws; p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
+  if (gemm16_supported(p)) launch_gemm16(p, s);
+  else throw std::logic_error("conv8: operand layout not supported by the fp8 GEMM");
+}
+
 // bf16 mode, DCT families: every GEMM input is a bf16 tensor written once by its producer (GroupNorm-apply pass,
 // previous GEMM epilogue, attention, DCT kernel), so both GEMM operands stream by LDS-DMA (gemm16.hip).
 // The fp32 tensors that carry the residual stream and the GroupNorm statistics stay fp32.
@@ -600,18 +635,23 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   const bool no_gn_fuse = exp_switch("DDPMIR_NO_GN_FUSE");
   IGemm probe = c1; probe.Cout = bw.conv1.cout16; probe.Cin = bw.conv1.cin16; probe.taps = bw.conv1.taps;
   const bool fuse_gn = !no_gn_fuse && gemm16_can_fuse_gn(probe, gn_groups(C));
-  launch_gn_apply16(in, ldin, B, HW, bw.cinp, p.sc1, p.sh1, ACT_NONE, p.a16, cin8, bw.has_shortcut ? p.x16 : nullptr,
-                    cin8, s, fuse_gn ? p.gn_sums : nullptr, fuse_gn ? B * gn_groups(C) * 2 : 0);
+  // (DDPMIR_FP8: the deep 3x3 convs take their operand as e4m3 instead -- written by the same pass)
+  const bool c1_f8 = bw.conv1.w8 != nullptr, c2_f8 = bw.conv2.w8 != nullptr, co_f8 = bw.conv_out.w8 != nullptr;
+  launch_gn_apply16(in, ldin, B, HW, bw.cinp, p.sc1, p.sh1, ACT_NONE, c1_f8 ? nullptr : p.a16, cin8, bw.has_shortcut ? p.x16 : nullptr,
+                    cin8, s, fuse_gn ? p.gn_sums : nullptr, fuse_gn ? B * gn_groups(C) * 2 : 0, c1_f8 ? p.a8 : nullptr, bw.conv1.cin16);
   if (fuse_gn) { c1.gn_sums = p.gn_sums; c1.gn_groups = gn_groups(C); }
-  conv16(bw.conv1, c1, s);
+  if (c1_f8) { c1.A16 = p.a8; c1.lda16 = bw.conv1.cin16; conv8(bw.conv1, c1, s); }
+  else conv16(bw.conv1, c1, s);
   // norm2 -> GELU -> conv2 ; hB also as bf16 for the qkv projection
   if (fuse_gn) launch_gn_from_sums(p.gn_sums, B, HW, C, gn_groups(C), bw.n2g, bw.n2b, p.sc2, p.sh2, s);
   else launch_gn_scale_shift(p.hA, C, B, HW, C, gn_groups(C), bw.n2g, bw.n2b, p.gn_partial, p.sc2, p.sh2, s);
-  launch_gn_apply16(p.hA, C, B, HW, C, p.sc2, p.sh2, ACT_GELU, p.a16, C, nullptr, 0, s);
+  launch_gn_apply16(p.hA, C, B, HW, C, p.sc2, p.sh2, ACT_GELU, c2_f8 ? nullptr : p.a16, C, nullptr, 0, s, nullptr, 0,
+                    c2_f8 ? p.a8 : nullptr, C);
   const bool attn = bw.level >= cfg.attn_min_level;
   IGemm c2 = g; c2.A16 = p.a16; c2.lda16 = C; c2.out = p.hB; c2.ldo = C;
   if (attn) { c2.out16 = p.hB16; c2.ldo16 = C; }
-  conv16(bw.conv2, c2, s);
+  if (c2_f8) { c2.A16 = p.a8; conv8(bw.conv2, c2, s); }
+  else conv16(bw.conv2, c2, s);
   if (attn) {
     // head_dim 16 levels: the projection's epilogue writes the attention operand images itself (no fp32 qkv round trip)
     const bool no_fuse = exp_switch("DDPMIR_NO_QKV_FUSE");
@@ -643,13 +683,15 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   const bool split_gates = exp_switch("DDPMIR_SPLIT_GATES");   // A/B: the four separate gate GEMMs
   if (cfg.arch == DDPMIR_ARCH_AVIF) {
     freq_avif(bw, H, W, s);                                            // -> plan_.S (fp32)
-    launch_gn_apply16(p.S, C, B, HW, C, nullptr, nullptr, ACT_NONE, p.S16, C, nullptr, 0, s);
+    launch_gn_apply16(p.S, C, B, HW, C, nullptr, nullptr, ACT_NONE, co_f8 ? nullptr : p.S16, C, nullptr, 0, s, nullptr, 0,
+                      co_f8 ? p.S8 : nullptr, C);
   } else if (!split_gates) {
     launch_block_transform(p.hB, C, p.xd, C, B, H, W, C, k.dct_block, bw.dct, 0, 0.f, 1.f, s, p.xdl16, nullptr, k.low_size);
     IGemm a = g; a.A16 = p.xdl16; a.lda16 = C; a.epi_act = ACT_LRELU; a.out16 = p.hid16; a.ldo16 = C;
     conv16(bw.fg1, a, s);
     IGemm d = g; d.A16 = p.hid16; d.lda16 = C; d.epi_act = ACT_SIGMOID; d.mul = p.xd; d.ldmul = C; d.sel_C = C;
-    d.rowscale = p.boost; d.res = p.hB; d.ldres = C; d.out16 = p.S16; d.ldo16 = C;
+    d.rowscale = p.boost; d.res = p.hB; d.ldres = C;
+    if (co_f8) { d.out8 = p.S8; d.ldo8 = C; } else { d.out16 = p.S16; d.ldo16 = C; }
     conv16(bw.fg2, d, s);
   } else {
     launch_block_transform(p.hB, C, p.xd, C, B, H, W, C, k.dct_block, bw.dct, 0, 0.f, 1.f, s, p.xdl16, p.xdh16, k.low_size);
@@ -661,14 +703,25 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
     IGemm c = a; c.A16 = p.xdh16;
     conv16(bw.high0, c, s);
     IGemm d = b2; d.epi_mask = MASK_HIGH; d.rowscale = p.boost; d.res = p.S; d.ldres = C; d.out = nullptr;
-    d.out16 = p.S16; d.ldo16 = C;
+    if (co_f8) { d.out8 = p.S8; d.ldo8 = C; } else { d.out16 = p.S16; d.ldo16 = C; }
     conv16(bw.high2, d, s);
   }
   // conv_out + residual; a 1x1 shortcut conv rides along as a second K segment of the same GEMM (identity shortcuts
   // are the plain fp32 residual)
   IGemm co = g; co.A16 = p.S16; co.lda16 = C; co.out = dest; co.ldo = lddest;
   const bool split_sc = exp_switch("DDPMIR_SPLIT_SHORTCUT");   // A/B: separate shortcut GEMM
-  if (bw.has_shortcut && !split_sc) {
+  if (co_f8) {
+    // e4m3 conv_out: a bf16 1x1 shortcut cannot share the MFMA type, so it runs as its own GEMM and comes back as residual
+    if (bw.has_shortcut) {
+      IGemm sc = g; sc.A16 = p.x16; sc.lda16 = cin8; sc.out = dest; sc.ldo = lddest;
+      conv16(bw.shortcut, sc, s);
+      co.res = dest; co.ldres = lddest;
+    } else {
+      co.res = in; co.ldres = ldin;
+    }
+    co.A16 = p.S8;
+    conv8(bw.conv_out, co, s);
+  } else if (bw.has_shortcut && !split_sc) {
     co.A16b = p.x16; co.lda16b = cin8; co.Wt16b = bw.shortcut.w16; co.Cinb = bw.shortcut.cin16;
     conv16(bw.conv_out, co, s, bw.co_bias);
   } else {
@@ -706,7 +759,7 @@ void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int 
     // algorithmic FLOPs of QK^T + PV: 4 * N^2 * C per image
     const double nn = (double)H * W;
     prof_begin(bw.level == 0 ? PROF_ATTN_L0 : PROF_ATTN, 4.0 * nn * nn * C * B, s);
-    if (cfg.dtype == DDPMIR_BF16 && attention_bf16_supported(H * W, C, k.heads))
+    if (use_gemm16() && attention_bf16_supported(H * W, C, k.heads))
       launch_attention_bf16(p.qkv, p.att, C, B, H * W, C, k.heads, p.attn_ws, s);
     else
       launch_attention(p.qkv, p.att, C, B, H * W, C, k.heads, s);

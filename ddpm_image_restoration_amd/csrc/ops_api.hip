@@ -1,4 +1,6 @@
 // Host-buffer single-operator entry points (include/ddpmir_ops.h) used by the per-operator parity tests.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -73,6 +75,32 @@ int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_
     for (int o = 0; o < Cout; ++o)
       for (int c = 0; c < Cin; ++c)
         for (int t = 0; t < taps; ++t) wp[((size_t)t * Cout + o) * cinp + c] = w_oihw[((size_t)o * Cin + c) * taps + t];
+    if (g_bf16 == 3) {
+      // fp8 variant of the DMA GEMM: x -> e4m3 by the operand pass, weights -> e4m3 with a per-tensor power-of-two scale
+      if (pro_mask != MASK_NONE || nchw_out || (Cout % 4) != 0 || (Cin % 16) != 0 || Cout <= 64) throw std::runtime_error("fp8 gemm op: unsupported shape");
+      float amax = 0.f;
+      for (float v : wp) amax = std::max(amax, std::fabs(v));
+      const int kexp = amax > 0.f ? (int)std::floor(std::log2(448.0 / (double)amax)) : 0;
+      std::vector<unsigned char> w8((size_t)taps * Cout * Cin, 0);
+      for (size_t i = 0; i < w8.size(); ++i) w8[i] = f32_to_e4m3(wp[i] * std::ldexp(1.0f, kexp));     // cinp == Cin here
+      float* dx = d.up(xp.data(), xp.size());
+      float *dsc = nullptr, *dsh = nullptr;
+      if (scale) { dsc = d.up(scale, (size_t)B * Cin); dsh = d.up(shift, (size_t)B * Cin); }
+      unsigned char* a8 = d.alloc<unsigned char>(M * Cin + 16);
+      launch_gn_apply16(dx, Cin, B, H * W, Cin, dsc, dsh, pro_act, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, a8, Cin);
+      IGemm p;
+      p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.taps = taps; p.bias = d.up(bias, Cout);
+      p.A16 = a8; p.lda16 = Cin; p.Wt16 = d.up(w8.data(), w8.size()); p.f8 = 1; p.acc_scale = std::ldexp(1.0f, -kexp);
+      p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); p.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
+      p.tb = d.up(tb, (size_t)B * Cout); p.ldtb = Cout; p.epi_act = epi_act; p.bs = bs; p.low = low;
+      p.mul = d.up(mul, M * Cout); p.ldmul = Cout; p.rowscale = d.up(rowscale, B); p.epi_mask = epi_mask;
+      p.res = d.up(res, M * Cout); p.ldres = Cout;
+      float* o = d.alloc<float>(M * Cout);
+      p.out = o; p.ldo = Cout; p.store = STORE_NHWC;
+      launch_gemm16(p, nullptr);
+      d.down(out, o, M * Cout);
+      return;
+    }
     if (g_bf16 == 2) {
       // DMA-streamed bf16 GEMM (gemm16.hip): operands pre-converted to bf16 by gn_apply16, channels padded to 8
       if (pro_mask != MASK_NONE || nchw_out || (Cout % 4) != 0) throw std::runtime_error("gemm16 op: unsupported options");
@@ -169,6 +197,17 @@ int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int b
       if (gelu_norm) { p.out16 = d.alloc<unsigned short>(M * Cout + 8); p.ldo16 = Cout; }
       gelu_norm = 0;
     }
+    if (bf16 == 3) {   // fp8 variant of the gemm16 path: e4m3 A tensor and weights made once outside the timed region
+      if (Cin % 16 || Cout <= 64) throw std::runtime_error("fp8 gemm timing needs Cin % 16 == 0 and Cout > 64");
+      unsigned char* a8 = d.alloc<unsigned char>(M * Cin + 16);
+      launch_gn_apply16(x, Cin, B, H * W, Cin, nullptr, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, a8, Cin);
+      std::vector<unsigned char> w8(wh.size());
+      for (size_t i = 0; i < wh.size(); ++i) w8[i] = f32_to_e4m3(wh[i] * 64.f);
+      p.A16 = a8; p.lda16 = Cin; p.Wt16 = d.up(w8.data(), w8.size()); p.f8 = 1; p.acc_scale = 1.f / 64.f;
+      p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); p.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
+      if (gelu_norm) { p.out8 = d.alloc<unsigned char>(M * Cout + 16); p.ldo8 = Cout; }
+      gelu_norm = 0;
+    }
     std::vector<float> ones((size_t)B * Cin, 1.0f), zeros((size_t)B * Cin, 0.1f), bias(Cout, 0.01f);
     p.bias = d.up(bias.data(), bias.size());
     if (gelu_norm) { p.scale = d.up(ones.data(), ones.size()); p.shift = d.up(zeros.data(), zeros.size()); p.pro_act = ACT_GELU; }
@@ -178,7 +217,7 @@ int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int b
     hipEvent_t a, b;
     DDPMIR_HIP_CHECK(hipEventCreate(&a));
     DDPMIR_HIP_CHECK(hipEventCreate(&b));
-    auto run = [&] { if (bf16 == 2) launch_gemm16(p, nullptr); else launch_igemm(p, nullptr); };
+    auto run = [&] { if (bf16 >= 2) launch_gemm16(p, nullptr); else launch_igemm(p, nullptr); };
     run();
     DDPMIR_HIP_CHECK(hipDeviceSynchronize());
     DDPMIR_HIP_CHECK(hipEventRecord(a, nullptr));

@@ -56,7 +56,7 @@ class _RestorationModel:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("the restoration model runs on a HIP device only (got %s)" % self.device)
-        self._cfg = _lib.Config(self.ARCH, {"f32": 0, "bf16": 1}[dtype], 0 if attn_levels == "all" else 5,
+        self._cfg = _lib.Config(self.ARCH, {"f32": 0, "bf16": 1, "fp8": 3}[dtype], 0 if attn_levels == "all" else 5,
                                 self.device.index or 0, int(use_graph))
         self._ctx = self._lib.ddpmir_create(C.byref(self._cfg))
         if not self._ctx:

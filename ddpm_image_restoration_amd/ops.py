@@ -71,7 +71,7 @@ def conv(x, w, bias=None, scale=None, shift=None, pro_act=None, pro_mask=None, b
          mul=None, rowscale=None, epi_mask=None, res=None, nchw_out=False, bf16=False, gate_select=0):
     lib = _lib_ops()
     lib.ddpmir_op_set_gate_select(int(gate_select))
-    lib.ddpmir_op_set_bf16(2 if bf16 == "dma" else int(bf16))
+    lib.ddpmir_op_set_bf16({"dma": 2, "fp8": 3}.get(bf16, int(bf16) if not isinstance(bf16, str) else 0))
     x, w = _f(x), _f(w)
     if w.ndim == 2:
         w = w[:, :, None, None]
@@ -90,7 +90,7 @@ def conv(x, w, bias=None, scale=None, shift=None, pro_act=None, pro_mask=None, b
 def conv_time(b, h, w, cin, cout, k, bf16=True, gelu_norm=False, residual=False, dbg=0, iters=5):
     lib = _lib_ops()
     ms = C.c_float(0)
-    _chk(lib, lib.ddpmir_op_conv_time(b, h, w, cin, cout, k, 2 if bf16 == "dma" else int(bf16), int(gelu_norm), int(residual), dbg, iters,
+    _chk(lib, lib.ddpmir_op_conv_time(b, h, w, cin, cout, k, {"dma": 2, "fp8": 3}.get(bf16, int(bf16) if not isinstance(bf16, str) else 0), int(gelu_norm), int(residual), dbg, iters,
                                       C.byref(ms)), "op_conv_time")
     return ms.value
 

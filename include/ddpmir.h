@@ -36,12 +36,16 @@ extern "C" {
 #define DDPMIR_F32 0
 #define DDPMIR_BF16 1
 #define DDPMIR_F16 2         /* storage type of checkpoint tensors only (ddpmir_load_tensor) */
+#define DDPMIR_FP8 3         /* arithmetic mode: DDPMIR_BF16 with OCP e4m3 operands (per-tensor power-of-two weight scale, unit
+                                activation scale) for the 3x3 convolutions with >= 256 input and output channels, on
+                                v_mfma_scale_f32_32x32x64_f8f6f4 -- the "fp8 MFMA deep convs" of BASELINE configs[4] */
 
 typedef struct ddpmir_ctx ddpmir_ctx;
 
 typedef struct ddpmir_config {
   int arch;            /* DDPMIR_ARCH_* */
-  int dtype;           /* DDPMIR_F32 (parity mode) | DDPMIR_BF16 (bf16 matrix-core operands, fp32 accumulation and storage) */
+  int dtype;           /* DDPMIR_F32 (parity mode) | DDPMIR_BF16 (bf16 matrix-core operands, fp32 accumulation and storage)
+                          | DDPMIR_FP8 (bf16 mode + e4m3 operands in the deep 3x3 convolutions) */
   int attn_min_level;  /* 0 = self-attention in all 13 blocks (the reference, webp_inference.py:317-321);
                           5 = bottleneck blocks only (the variant BASELINE.json's configs describe) */
   int device;          /* HIP device ordinal */

@@ -404,3 +404,41 @@ def test_conv_bf16_dma_fused_epilogue(ops):
 
 
 
+
+
+def test_conv_fp8_operand_layout_is_exact_on_integer_data(ops):
+    """DDPMIR_FP8 convs (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 operands by LDS-DMA): with operands that are exactly
+    representable in e4m3 (small integers; weights = small integers * 2^-k, undone by the power-of-two tensor scale) every
+    product and partial sum is exact in fp32, so the result must EQUAL the fp32 convolution -- an asymmetric pattern that
+    any wrong lane / k mapping, swizzle or tap order breaks.  3x3 and 1x1, ragged M, two K-chunk counts."""
+    rng = np.random.default_rng(11)
+    for (b, h, w, cin, cout, k) in ((2, 8, 12, 256, 128, 3), (1, 5, 7, 320, 96, 3), (3, 16, 16, 512, 256, 1)):
+        x = rng.integers(-4, 5, (b, h, w, cin)).astype(np.float32)
+        wt = (rng.integers(-3, 4, (cout, cin, k, k)) * 0.125).astype(np.float32)
+        wt[0, 0, 0, 0] = 0.375                                   # |w| max fixed -> the tensor scale is a known power of two
+        bias = rng.integers(-2, 3, cout).astype(np.float32)
+        ref = O.conv2d(x.transpose(0, 3, 1, 2), wt, bias, k // 2).transpose(0, 2, 3, 1)
+        got = ops.conv(x, wt, bias, bf16="fp8")
+        assert np.array_equal(got, ref), (b, h, w, cin, cout, k, float(np.abs(got - ref).max()))
+
+
+def test_conv_fp8_against_quantised_oracle(ops):
+    """Random data: the fp8 conv equals the fp32 conv of the e4m3-rounded operands to accumulation-order accuracy, and is
+    within e4m3's 2^-4 relative operand error of the unquantised conv."""
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((2, 16, 16, 256)).astype(np.float32)
+    wt = (rng.standard_normal((256, 256, 3, 3)) * 0.02).astype(np.float32)
+    bias = rng.standard_normal(256).astype(np.float32) * 0.1
+
+    def e4m3(a):   # round to nearest even onto the e4m3 grid (3 mantissa bits, min normal 2^-6, subnormal step 2^-9, max 448)
+        a = np.clip(a.astype(np.float64), -448, 448)
+        e = np.floor(np.log2(np.maximum(np.abs(a), 2.0 ** -20)))
+        q = np.where(e < -6, 2.0 ** -9, 2.0 ** (e - 3))
+        return (np.rint(a / q) * q).astype(np.float32)
+    kexp = np.floor(np.log2(448.0 / np.abs(wt).max()))
+    wq = e4m3(wt * 2.0 ** kexp) * 2.0 ** -kexp
+    ref_q = O.conv2d(e4m3(x).transpose(0, 3, 1, 2), wq.astype(np.float32), bias, 1).transpose(0, 2, 3, 1)
+    ref = O.conv2d(x.transpose(0, 3, 1, 2), wt, bias, 1).transpose(0, 2, 3, 1)
+    got = ops.conv(x, wt, bias, bf16="fp8")
+    assert np.abs(got - ref_q).max() < 2e-4 * np.abs(ref).max()
+    assert np.abs(got - ref).mean() < 0.05 * np.abs(ref).mean()
