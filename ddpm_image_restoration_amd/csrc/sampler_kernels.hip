@@ -224,44 +224,78 @@ __global__ __launch_bounds__(256) void dft_cols_k(const float* __restrict__ in_r
 // DFT (error ~ N eps) then disagrees with the reference's FFT (error ~ log N eps) about the sign of such a bin and the image
 // leaves the reference trajectory at its first phase fix.  This transform runs once per sample() call, so it is simply
 // done in double: rows, then columns fused with the normalisation to the unit phase (fp32 out).
-__global__ void dft_rows_f64_k(const float* __restrict__ in, double* __restrict__ out_re, double* __restrict__ out_im, int W,
-                               int64_t nrows, const double* __restrict__ cs, const double* __restrict__ sn) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= nrows * W) return;
-  const int64_t row = gid / W;
-  const int v = (int)(gid - row * W);
-  const float* src = in + row * W;
-  double ar = 0.0, ai = 0.0;
-  int idx = 0;
-  for (int x = 0; x < W; ++x) {
-    const double a = (double)src[x];
-    ar = fma(a, cs[idx], ar);
-    ai = fma(-a, sn[idx], ai);          // e^{-2 pi i v x / W}
-    idx += v; if (idx >= W) idx -= W;
+// rows: one workgroup per RB64 = 4 rows; the rows and the twiddle tables sit in LDS (doubles), thread = output bin v
+constexpr int DFT64_RB = 4;
+__global__ __launch_bounds__(256) void dft_rows_f64_k(const float* __restrict__ in, double* __restrict__ out_re, double* __restrict__ out_im, int W,
+                                                      int64_t nrows, const double* __restrict__ cs, const double* __restrict__ sn) {
+  extern __shared__ __attribute__((aligned(16))) double sh64[];
+  double* xr = sh64; double* tc = sh64 + DFT64_RB * W; double* ts = tc + W;      // xr[x][RB]
+  const int64_t row0 = (int64_t)blockIdx.x * DFT64_RB;
+  for (int i = threadIdx.x; i < DFT64_RB * W; i += 256) {
+    const int r = i / W, x = i - r * W;
+    xr[x * DFT64_RB + r] = row0 + r < nrows ? (double)in[(row0 + r) * W + x] : 0.0;
   }
-  out_re[gid] = ar; out_im[gid] = ai;
+  for (int x = threadIdx.x; x < W; x += 256) { tc[x] = cs[x]; ts[x] = sn[x]; }
+  __syncthreads();
+  for (int v = threadIdx.x; v < W; v += 256) {
+    double ar[DFT64_RB], ai[DFT64_RB];
+#pragma unroll
+    for (int r = 0; r < DFT64_RB; ++r) { ar[r] = 0.0; ai[r] = 0.0; }
+    int idx = 0;
+    for (int x = 0; x < W; ++x) {
+      const double c = tc[idx], sv = ts[idx];          // e^{-2 pi i v x / W} = c - i sv
+#pragma unroll
+      for (int r = 0; r < DFT64_RB; ++r) {
+        const double a = xr[x * DFT64_RB + r];
+        ar[r] = fma(a, c, ar[r]);
+        ai[r] = fma(-a, sv, ai[r]);
+      }
+      idx += v; if (idx >= W) idx -= W;
+    }
+#pragma unroll
+    for (int r = 0; r < DFT64_RB; ++r)
+      if (row0 + r < nrows) { out_re[(row0 + r) * W + v] = ar[r]; out_im[(row0 + r) * W + v] = ai[r]; }
+  }
 }
-__global__ void dft_cols_unit_f64_k(const double* __restrict__ in_re, const double* __restrict__ in_im, float* __restrict__ ure,
-                                    float* __restrict__ uim, int H, int W, int64_t total, const double* __restrict__ cs,
-                                    const double* __restrict__ sn) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (plane, u, x), x fastest
-  if (gid >= total) return;
-  const int x = (int)(gid % W);
-  const int u = (int)((gid / W) % H);
-  const int64_t p = gid / ((int64_t)W * H);
-  const double* br = in_re + p * H * W + x;
-  const double* bi = in_im + p * H * W + x;
-  double ar = 0.0, ai = 0.0;
-  int idx = 0;
+// columns fused with the normalisation to the unit phase: workgroup = (plane, 64-wide x strip, 4 x 8 output rows); lane =
+// x (coalesced), every wave owns 8 output rows u whose twiddles are wave-uniform LDS reads
+constexpr int DFT64_UB = 8;
+__global__ __launch_bounds__(256) void dft_cols_unit_f64_k(const double* __restrict__ in_re, const double* __restrict__ in_im,
+                                                           float* __restrict__ ure, float* __restrict__ uim, int H, int W,
+                                                           const double* __restrict__ cs, const double* __restrict__ sn) {
+  extern __shared__ __attribute__((aligned(16))) double sh64[];
+  double* tc = sh64; double* ts = sh64 + H;
+  for (int y = threadIdx.x; y < H; y += 256) { tc[y] = cs[y]; ts[y] = -sn[y]; }
+  __syncthreads();
+  const int p = blockIdx.z;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int u0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * DFT64_UB;
+  if (x >= W || u0 >= H) return;
+  const double* br = in_re + (size_t)p * H * W + x;
+  const double* bi = in_im + (size_t)p * H * W + x;
+  double ar[DFT64_UB], ai[DFT64_UB];
+  int idx[DFT64_UB], inc[DFT64_UB];
+#pragma unroll
+  for (int j = 0; j < DFT64_UB; ++j) { ar[j] = 0.0; ai[j] = 0.0; idx[j] = 0; inc[j] = u0 + j < H ? u0 + j : 0; }
   for (int y = 0; y < H; ++y) {
-    const double vr = br[(size_t)y * W], vi = bi[(size_t)y * W], c = cs[idx], sv = -sn[idx];
-    ar += vr * c - vi * sv;
-    ai += vr * sv + vi * c;
-    idx += u; if (idx >= H) idx -= H;
+    const double vr = br[(size_t)y * W], vi = bi[(size_t)y * W];
+#pragma unroll
+    for (int j = 0; j < DFT64_UB; ++j) {
+      const double c = tc[idx[j]], sv = ts[idx[j]];
+      ar[j] += vr * c - vi * sv;
+      ai[j] += vr * sv + vi * c;
+      idx[j] += inc[j]; if (idx[j] >= H) idx[j] -= H;
+    }
   }
-  const double mag = sqrt(ar * ar + ai * ai);
-  if (mag > 0.0) { ure[gid] = (float)(ar / mag); uim[gid] = (float)(ai / mag); }
-  else { ure[gid] = 1.f; uim[gid] = 0.f; }    // angle(0) = atan2(0,0) = 0
+#pragma unroll
+  for (int j = 0; j < DFT64_UB; ++j) {
+    const int u = u0 + j;
+    if (u >= H) break;
+    const size_t o = ((size_t)p * H + u) * W + x;
+    const double mag = sqrt(ar[j] * ar[j] + ai[j] * ai[j]);
+    if (mag > 0.0) { ure[o] = (float)(ar[j] / mag); uim[o] = (float)(ai[j] / mag); }
+    else { ure[o] = 1.f; uim[o] = 0.f; }    // angle(0) = atan2(0,0) = 0
+  }
 }
 
 __global__ void unit_phase_k(float* re, float* im, int64_t n) {
@@ -403,11 +437,13 @@ void launch_phase_apply_inverse(const float* x, const float* xre, const float* x
 
 void launch_ref_unit_phase_f64(const float* y, float* ure, float* uim, double* tmp_re, double* tmp_im, int P, const DftPlan64& d,
                                hipStream_t s) {
-  const int64_t total = (int64_t)P * d.H * d.W;
-  const unsigned blocks = (unsigned)cdiv64(total, 256);
-  hipLaunchKernelGGL(dft_rows_f64_k, dim3(blocks), dim3(256), 0, s, y, tmp_re, tmp_im, d.W, (int64_t)P * d.H, d.cos_w, d.sin_w);
-  hipLaunchKernelGGL(dft_cols_unit_f64_k, dim3(blocks), dim3(256), 0, s, (const double*)tmp_re, (const double*)tmp_im, ure, uim,
-                     d.H, d.W, total, d.cos_h, d.sin_h);
+  const int64_t nrows = (int64_t)P * d.H;
+  const size_t lds_r = (size_t)(DFT64_RB + 2) * d.W * sizeof(double), lds_c = (size_t)2 * d.H * sizeof(double);
+  if (lds_r > 64 * 1024 || lds_c > 64 * 1024) throw std::invalid_argument("phase_consistency: image too large for the fp64 reference-phase kernels");
+  hipLaunchKernelGGL(dft_rows_f64_k, dim3((unsigned)cdiv64(nrows, DFT64_RB)), dim3(256), lds_r, s, y, tmp_re, tmp_im, d.W, nrows, d.cos_w,
+                     d.sin_w);
+  hipLaunchKernelGGL(dft_cols_unit_f64_k, dim3(cdiv(d.W, 64), cdiv(d.H, 4 * DFT64_UB), P), dim3(256), lds_c, s, (const double*)tmp_re,
+                     (const double*)tmp_im, ure, uim, d.H, d.W, d.cos_h, d.sin_h);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

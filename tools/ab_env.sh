@@ -1,4 +1,7 @@
 # usage: bash tools/ab_env.sh VAR   -> runs bench with and without VAR=1 in the same box, prints rest-of-forward ms
+# The A/B switches only exist in the experiments build: python -m ddpm_image_restoration_amd.build --experiments
+# (-> ddpm_image_restoration_amd/libddpmir_exp.so, selected here through DDPMIR_LIB_PATH)
+export DDPMIR_LIB_PATH=${DDPMIR_LIB_PATH:-$(dirname $0)/../ddpm_image_restoration_amd/libddpmir_exp.so}
 for v in "" "1"; do
   if [ -n "$v" ]; then export $1=1; else unset $1; fi
   python3 bench.py --steps 10 2>/dev/null | python3 -c "

@@ -8,6 +8,7 @@ res = {v: [] for v in variants}
 for rnd in range(3):
     for v in variants:
         env = dict(os.environ, DDPMIR_ATTN_VARIANT=v)
+        env.setdefault("DDPMIR_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ddpm_image_restoration_amd", "libddpmir_exp.so"))   # variants exist in the experiments build only
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip().split("\n")[-1]
         res[v].append(float(out))
 for v in variants:
