@@ -442,3 +442,33 @@ def test_conv_fp8_against_quantised_oracle(ops):
     got = ops.conv(x, wt, bias, bf16="fp8")
     assert np.abs(got - ref_q).max() < 2e-4 * np.abs(ref).max()
     assert np.abs(got - ref).mean() < 0.05 * np.abs(ref).mean()
+
+
+def test_attention_bf16_no_max_and_general_kernels(ops):
+    """head_dim <= 16: pairs whose scores are bounded (|q||k| <= 100 in log2 units) run in the kernel without a running
+    max, the others in the general kernel with the deferred rescale; a flag per (batch, head) routes them.  A batch that
+    mixes both -- image 0 ordinary activations, image 1 with q, k scaled up until scores reach +-150 (a nearly one-hot
+    softmax) -- must agree for every pair with softmax attention evaluated on the SAME bf16-rounded operands (the rounding
+    of q and k moves such logits by ~0.3, so the unrounded softmax is not the yardstick there); also head_dim 8."""
+    rng = np.random.default_rng(21)
+
+    def bf16(a):
+        u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    for heads, C in ((4, 64), (8, 64)):
+        B, N, d = 2, 2048, C // heads
+        qkv = rng.standard_normal((B, N, 3 * C)).astype(np.float32)
+        qkv[1, :, :2 * C] *= 6.0
+        qkv[1, 7, C:C + d] = qkv[1, 3, :d] * 2.0                          # one dominant key for query 3 of head 0
+        q, k, v = (qkv[..., i * C:(i + 1) * C].reshape(B, N, heads, d).transpose(0, 2, 1, 3) for i in range(3))
+        qr = bf16(q * np.float32(1.4426950408889634 / np.sqrt(d))).astype(np.float64)
+        kr, vr = bf16(k).astype(np.float64), bf16(v).astype(np.float64)
+        s2 = qr @ kr.transpose(0, 1, 3, 2)                                # log2 units
+        assert np.abs(s2[0]).max() < 100 < np.abs(s2[1]).max()            # image 0 is bounded, image 1 is not
+        p = np.exp2(s2 - s2.max(-1, keepdims=True))
+        ref = ((p / p.sum(-1, keepdims=True)) @ vr).transpose(0, 2, 1, 3).reshape(B, N, C).astype(np.float32)
+        got = ops.attention(qkv, heads, bf16=True)
+        assert np.isfinite(got).all()
+        for b in range(B):
+            e = np.abs(got[b] - ref[b])
+            assert e.max() < 3e-2 and e.mean() < 2e-3, (heads, b, e.max(), e.mean())
