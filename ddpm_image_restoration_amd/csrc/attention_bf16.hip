@@ -128,6 +128,14 @@ __global__ __launch_bounds__(256) void pack_qkv_bf16(const float* __restrict__ q
 
 // ------------------------------------------------------------------------------------------------ flash
 constexpr float RESCALE_THR = 20.0f;   // log2 units
+// score bound of a (batch, head) pair below which the softmax needs no running max (flash_bf16_nm, further down)
+constexpr float NM_BOUND = 80.0f;      // log2 units
+struct PairBounds { unsigned qmax2, kmax; };   // fp32 bit patterns of max |q|^2 and max |k|
+__device__ __forceinline__ bool pair_is_bounded(const PairBounds* bounds, int bh) {
+  const float q2 = __uint_as_float(bounds[bh].qmax2), km = __uint_as_float(bounds[bh].kmax);
+  return sqrtf(q2) * 1.002f * km <= NM_BOUND;
+}
+
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -135,7 +143,7 @@ template <int D, int QS, int TS, int WPS = 0, int DMA = 1, int DEN = 0>
 __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
                                                   const float* __restrict__ Kmax, float* __restrict__ out, int ldo,
                                                   int N, int NT, int heads, int nqb, int npairs,
-                                                  __bf16* __restrict__ out16, const unsigned char* __restrict__ skip) {
+                                                  __bf16* __restrict__ out16, const PairBounds* __restrict__ skip) {
   using G = AttnGeom<D>;
   using SG = StageGeom<D, TS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 stage buffers
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
     bh = wg / nqb;
     qb = wg - bh * nqb;
   }
-  if (skip && skip[bh]) return;        // bounded scores: this pair ran in the no-max kernel (flash_bf16_nm)
+  if (skip && pair_is_bounded(skip, bh)) return;        // bounded scores: this pair ran in the no-max kernel (flash_bf16_nm)
   const int b = bh / heads, head = bh - b * heads;
   const int q0 = qb * (128 * QS) + wave * (32 * QS);
 
@@ -439,23 +447,24 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
 // ------------------------------------------------------------------------------------------------ flash, no running max
 // Softmax needs the running max only to keep exp() in range.  When the scores of a whole (batch, head) pair are bounded
 // -- |s| <= |q|max |k|max <= NM_BOUND in log2 units, known from the per-tile norms the packers emit -- p = 2^s itself is
-// safe: p in [2^-100, 2^100], sums of 2^18 terms and the PV accumulators stay far inside fp32's range, and bf16 / fp32
+// safe: p in [2^-80, 2^80], sums of 2^18 terms and the PV accumulators (times |v| up to 2^30) stay inside fp32's range, and bf16 / fp32
 // relative precision does not depend on the scale.  This variant therefore runs with NO max: the S^T MFMA accumulates
 // onto the constant 0 (no 16-register -m tile per query sub-tile), there is no bound test, no vote, no rescale path, and
-// the kernel fits three waves per SIMD (the general kernel: 226 VGPRs, two).  A flag per pair (attn_safe_flags_k) routes
+// the kernel fits three waves per SIMD (the general kernel: 229 VGPRs, two).  The pair's score bound (attn_pair_bounds_k) routes
 // each pair to exactly one of the two kernels; both are always launched and the workgroups of the other one return at once.
-constexpr float NM_BOUND = 100.0f;
 
-// flags[bh] = 1 when every score of the pair is bounded: max|q| * max|k| <= NM_BOUND (norms of the bf16 operands as the MFMA
-// sees them; q carries log2(e)/sqrt(d)).  One workgroup per pair streams its Q image once (2 MiB at 65 536 tokens).
+// bounds[bh] = { max |q|^2 , max |k| } of a (batch, head) pair as fp32 bit patterns (non-negative floats order like
+// unsigned integers, so partial maxima fold with atomicMax).  Norms of the bf16 operands as the MFMA sees them; q carries
+// log2(e)/sqrt(d); the per-tile |k| bounds come from the packers.  Grid (slices, pairs); cleared by a memset node before.
 template <int DP>
-__global__ __launch_bounds__(256) void attn_safe_flags_k(const __bf16* __restrict__ Qp, const float* __restrict__ Kmax, int NT,
-                                                         unsigned char* __restrict__ flags) {
+__global__ __launch_bounds__(256) void attn_pair_bounds_k(const __bf16* __restrict__ Qp, const float* __restrict__ Kmax, int NT,
+                                                          PairBounds* __restrict__ bounds) {
   __shared__ float rq[4], rk[4];
-  const int bh = blockIdx.x, tid = threadIdx.x;
+  const int bh = blockIdx.y, tid = threadIdx.x, nsl = gridDim.x, sl = blockIdx.x;
   const __bf16* q = Qp + (size_t)bh * NT * 32 * DP;
+  const int rows = NT * 32, r0 = (int)((long long)rows * sl / nsl), r1 = (int)((long long)rows * (sl + 1) / nsl);
   float m = 0.f;
-  for (int r = tid; r < NT * 32; r += 256) {
+  for (int r = r0 + tid; r < r1; r += 256) {
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < DP; c += 8) {
@@ -466,7 +475,8 @@ __global__ __launch_bounds__(256) void attn_safe_flags_k(const __bf16* __restric
     m = fmaxf(m, ss);
   }
   float km = 0.f;
-  for (int t = tid; t < NT; t += 256) km = fmaxf(km, Kmax[(size_t)bh * NT + t]);
+  const int t0 = (int)((long long)NT * sl / nsl), t1 = (int)((long long)NT * (sl + 1) / nsl);
+  for (int t = t0 + tid; t < t1; t += 256) km = fmaxf(km, Kmax[(size_t)bh * NT + t]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { m = fmaxf(m, __shfl_xor(m, off)); km = fmaxf(km, __shfl_xor(km, off)); }
   if ((tid & 63) == 0) { rq[tid >> 6] = m; rk[tid >> 6] = km; }
@@ -474,13 +484,15 @@ __global__ __launch_bounds__(256) void attn_safe_flags_k(const __bf16* __restric
   if (tid == 0) {
     m = fmaxf(fmaxf(rq[0], rq[1]), fmaxf(rq[2], rq[3]));
     km = fmaxf(fmaxf(rk[0], rk[1]), fmaxf(rk[2], rk[3]));
-    flags[bh] = (sqrtf(m) * 1.002f * km <= NM_BOUND) ? 1 : 0;     // (NaN compares false: goes to the general kernel)
+    if (!(m == m) || !(km == km)) { m = INFINITY; km = INFINITY; }          // NaN operands: route to the general kernel
+    atomicMax(&bounds[bh].qmax2, __float_as_uint(m));
+    atomicMax(&bounds[bh].kmax, __float_as_uint(km));
   }
 }
 
 template <int D, int QS, int TS>
 __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
-                                                        const unsigned char* __restrict__ safe, float* __restrict__ out, int ldo,
+                                                        const PairBounds* __restrict__ bounds, float* __restrict__ out, int ldo,
                                                         int N, int NT, int heads, int nqb, int npairs, __bf16* __restrict__ out16) {
   using G = AttnGeom<D>;
   using SG = StageGeom<D, TS>;
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
     bh = wg / nqb;
     qb = wg - bh * nqb;
   }
-  if (!safe[bh]) return;                                   // this pair goes through the general kernel
+  if (!pair_is_bounded(bounds, bh)) return;                // this pair goes through the general kernel
   const int b = bh / heads, head = bh - b * heads;
   const int q0 = qb * (128 * QS) + wave * (32 * QS);
   bf16x8 qf[QS];
@@ -615,12 +627,13 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
     DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16<D, QS, TS, WPS, DMA, DEN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SG::STAGE_BYTES + 2 * TS * 4));
   });
-  const unsigned char* skip = nullptr;
+  const PairBounds* skip = nullptr;
   if constexpr (NMTS > 0) {
-    // pairs with bounded scores run without a running max (three or four waves per SIMD); the general kernel takes the rest
+    // pairs with bounded scores run without a running max (three waves per SIMD); the general kernel takes the rest
     using SN = StageGeom<D, NMTS>;
-    unsigned char* flags = reinterpret_cast<unsigned char*>(Kmax + (size_t)BH * NT);
-    hipLaunchKernelGGL(attn_safe_flags_k<G::DP>, dim3(BH), dim3(256), 0, s, (const __bf16*)Qp, (const float*)Kmax, NT, flags);
+    PairBounds* flags = reinterpret_cast<PairBounds*>(Kmax + (size_t)BH * NT);
+    DDPMIR_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)BH * sizeof(PairBounds), s));
+    hipLaunchKernelGGL(attn_pair_bounds_k<G::DP>, dim3(NT >= 256 ? 32 : 1, BH), dim3(256), 0, s, (const __bf16*)Qp, (const float*)Kmax, NT, flags);
     static PerDeviceOnce attr_nm;
     attr_nm.run([] {
       DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16_nm<D, NMQS, NMTS>),
@@ -628,7 +641,7 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
     });
     const int nqb_nm = (N + 128 * NMQS - 1) / (128 * NMQS);
     hipLaunchKernelGGL((flash_bf16_nm<D, NMQS, NMTS>), dim3((unsigned)(nqb_nm * BH)), dim3(256), 2 * SN::STAGE_BYTES, s, (const __bf16*)Qp,
-                       (const unsigned char*)KVp, (const unsigned char*)flags, out, ldo, N, NT, heads, nqb_nm, BH, reinterpret_cast<__bf16*>(out16));
+                       (const unsigned char*)KVp, (const PairBounds*)flags, out, ldo, N, NT, heads, nqb_nm, BH, reinterpret_cast<__bf16*>(out16));
     skip = flags;
   }
   hipLaunchKernelGGL((flash_bf16<D, QS, TS, WPS, DMA, DEN>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
@@ -641,7 +654,7 @@ size_t ws_bytes_for(int B, int N, int heads) {
   using G = AttnGeom<D>;
   const size_t NT = (N + 31) / 32, BH = (size_t)B * heads;
   return ((BH * NT * 32 * G::DP * 2 + 255) & ~size_t(255)) + ((BH * NT * G::TILE_BYTES + 255) & ~size_t(255)) +
-         BH * NT * 4 + BH + 256;       // ... + per-tile |k| bounds + one no-max flag per (batch, head)
+         BH * NT * 4 + BH * 8 + 256;   // ... + per-tile |k| bounds + the score bounds of every (batch, head) pair
 }
 
 }  // namespace

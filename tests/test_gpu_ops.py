@@ -445,7 +445,7 @@ def test_conv_fp8_against_quantised_oracle(ops):
 
 
 def test_attention_bf16_no_max_and_general_kernels(ops):
-    """head_dim <= 16: pairs whose scores are bounded (|q||k| <= 100 in log2 units) run in the kernel without a running
+    """head_dim <= 16: pairs whose scores are bounded (|q||k| <= 80 in log2 units) run in the kernel without a running
     max, the others in the general kernel with the deferred rescale; a flag per (batch, head) routes them.  A batch that
     mixes both -- image 0 ordinary activations, image 1 with q, k scaled up until scores reach +-150 (a nearly one-hot
     softmax) -- must agree for every pair with softmax attention evaluated on the SAME bf16-rounded operands (the rounding
@@ -464,7 +464,7 @@ def test_attention_bf16_no_max_and_general_kernels(ops):
         qr = bf16(q * np.float32(1.4426950408889634 / np.sqrt(d))).astype(np.float64)
         kr, vr = bf16(k).astype(np.float64), bf16(v).astype(np.float64)
         s2 = qr @ kr.transpose(0, 1, 3, 2)                                # log2 units
-        assert np.abs(s2[0]).max() < 100 < np.abs(s2[1]).max()            # image 0 is bounded, image 1 is not
+        assert np.abs(s2[0]).max() < 80 < np.abs(s2[1]).max()            # image 0 is bounded, image 1 is not
         p = np.exp2(s2 - s2.max(-1, keepdims=True))
         ref = ((p / p.sum(-1, keepdims=True)) @ vr).transpose(0, 2, 1, 3).reshape(B, N, C).astype(np.float32)
         got = ops.attention(qkv, heads, bf16=True)

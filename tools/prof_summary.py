@@ -17,7 +17,9 @@ for k, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
     print(f"{k[:60]:60s} calls/fwd={c/n_fwd:6.1f} ms/fwd={us/1e3/n_fwd:8.3f}")
 # the roofline kernel: level-0 attention launches only (the largest grid of flash_bf16<16,...>); bench.py's
 # roofline.avg_launch_ms is the HIP-event average of exactly these dispatches
-fl = [r for r in rows if "flash_bf16<" in r["Kernel_Name"]]
+fl = [r for r in rows if "flash_bf16" in r["Kernel_Name"]]
+if any("flash_bf16_nm" in r["Kernel_Name"] for r in fl):   # bounded scores run in the no-max kernel; the general kernel's
+    fl = [r for r in fl if "flash_bf16_nm" in r["Kernel_Name"]]   # workgroups of those pairs return at once
 if fl:
     gmax = max(int(r["Grid_Size_X"]) for r in fl)
     l0 = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in fl if int(r["Grid_Size_X"]) == gmax]
