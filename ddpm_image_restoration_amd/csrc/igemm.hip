@@ -194,7 +194,7 @@ constexpr int BK16 = 64;
 constexpr int LROW16 = BK16 * 2 + 16;   // bytes
 
 template <int NT, int STAGES>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
+__device__ __forceinline__ void igemm_bf16_body(const IGemm& p, const int bx, const int by, const int nsplit, const int sk) {
   // STAGES == 2: two LDS stages: chunk i is consumed by the MFMAs while chunk i+1 is written and chunk i+2 is in flight
   // from global memory into registers -> one barrier per chunk and a full chunk of latency cover.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -207,12 +207,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
   const int r0 = tid >> 3;
   const int M = p.B * p.H * p.W;
   const int HW = p.H * p.W;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * (NT * 32);
+  const int m0 = bx * BM;
+  const int n0 = by * (NT * 32);
   const int nck = (p.Cin + BK16 - 1) / BK16;
   const int nit_all = p.taps * nck;
   // split-K: this workgroup owns iterations [it0, it1) of the (tap, chunk) space
-  const int nsplit = gridDim.z, sk = blockIdx.z;
   const int it0 = (int)((long long)nit_all * sk / nsplit), it1 = (int)((long long)nit_all * (sk + 1) / nsplit);
   const int nit = it1 - it0;
   const bool affine = p.scale != nullptr;
@@ -490,6 +489,22 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
 }
 
 // zero an [M][C] slice of a strided tensor (split-K accumulation target)
+template <int NT, int STAGES>
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm p) {
+  igemm_bf16_body<NT, STAGES>(p, blockIdx.x, blockIdx.y, gridDim.z, blockIdx.z);
+}
+
+// Up to four independent small problems of the same (Cout, Cin, taps) in ONE launch (blockIdx.z selects the problem):
+// the AVIF block's pooled gates are four S x S maps (S = 1, 2, 4, 8) with their own weights, each a latency-bound GEMM of a
+// few rows -- 8 launches of ~30 us per block become 2.
+struct IGemmGroup { IGemm p[4]; int gx[4]; };
+template <int NT, int STAGES>
+__global__ __launch_bounds__(256) void igemm_bf16_group_kernel(const IGemmGroup g) {
+  const int i = blockIdx.z;
+  if ((int)blockIdx.x >= g.gx[i]) return;
+  igemm_bf16_body<NT, STAGES>(g.p[i], blockIdx.x, blockIdx.y, 1, 0);
+}
+
 __global__ void zero_rows_k(float* out, int ldo, int64_t M, int C4) {
   const int64_t total = M * C4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -534,6 +549,48 @@ void launch_bf16(const IGemm& p, int64_t M, hipStream_t stream) {
 }
 
 }  // namespace
+
+template <int NT>
+void launch_bf16_group(const IGemm* ps, int n, hipStream_t stream) {
+  constexpr int EPI = 4 * 32 * (NT * 32 + 4) * 4;
+  constexpr int LDS1 = (BM + NT * 32) * LROW16 > EPI ? (BM + NT * 32) * LROW16 : EPI;
+  constexpr int LDS = 2 * (BM + NT * 32) * LROW16;
+  static PerDeviceOnce attr;
+  attr.run([] {
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_group_kernel<NT, 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_group_kernel<NT, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS1));
+  });
+  IGemmGroup g;
+  int gxmax = 1;
+  for (int i = 0; i < 4; ++i) {
+    g.p[i] = ps[i < n ? i : 0];
+    g.gx[i] = i < n ? (int)cdiv64((int64_t)ps[i].B * ps[i].H * ps[i].W, BM) : 0;
+    gxmax = std::max(gxmax, g.gx[i]);
+  }
+  const int gy = cdiv(ps[0].Cout, NT * 32), nit = ps[0].taps * cdiv(ps[0].Cin, BK16);
+  if (nit <= 18) hipLaunchKernelGGL((igemm_bf16_group_kernel<NT, 1>), dim3(gxmax, gy, n), dim3(256), LDS1, stream, g);
+  else hipLaunchKernelGGL((igemm_bf16_group_kernel<NT, 2>), dim3(gxmax, gy, n), dim3(256), LDS, stream, g);
+}
+
+void launch_igemm_group(const IGemm* ps, int n, hipStream_t stream) {
+  bool same = n >= 1 && n <= 4 && ps[0].Wt16 != nullptr;
+  for (int i = 1; i < n && same; ++i)
+    same = ps[i].Wt16 && ps[i].Cout == ps[0].Cout && ps[i].Cin == ps[0].Cin && ps[i].taps == ps[0].taps;
+  if (!same || n == 1) {            // fp32 parity path, or nothing to group
+    for (int i = 0; i < n; ++i) launch_igemm(ps[i], stream);
+    return;
+  }
+  for (int i = 0; i < n; ++i) {
+    if (ps[i].Cin % 4 != 0 || ps[i].lda % 4 != 0) throw std::runtime_error("igemm: Cin and lda must be multiples of 4");
+    if (ps[i].pro_mask != MASK_NONE && ps[i].taps != 1) throw std::runtime_error("igemm: input mask needs taps == 1");
+  }
+  if (ps[0].Cout <= 32) launch_bf16_group<1>(ps, n, stream);
+  else if (ps[0].Cout <= 64) launch_bf16_group<2>(ps, n, stream);
+  else launch_bf16_group<4>(ps, n, stream);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
 
 void launch_igemm(const IGemm& p, hipStream_t stream) {
   if (p.Cin % 4 != 0 || p.lda % 4 != 0) throw std::runtime_error("igemm: Cin and lda must be multiples of 4");

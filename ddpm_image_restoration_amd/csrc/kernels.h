@@ -63,6 +63,8 @@ struct IGemm {
   int dbg = 0;   // timing experiments only: 1 skip A loads, 2 skip B loads, 4 skip MFMA, 8 skip stores, 16 skip LDS writes
 };
 void launch_igemm(const IGemm& p, hipStream_t stream);
+// up to four problems of equal (Cout, Cin, taps) in one launch (bf16 path; falls back to a loop otherwise)
+void launch_igemm_group(const IGemm* ps, int n, hipStream_t stream);
 bool gemm16_supported(const IGemm& p);
 void launch_gemm16(const IGemm& p, hipStream_t stream);
 bool gemm16_can_fuse_gn(const IGemm& p, int groups);   // p as it will be launched (without gn_sums)

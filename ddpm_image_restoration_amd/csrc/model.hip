@@ -340,7 +340,7 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
   p.qkv = a.take<float>(mc * 3);
   if (avif) {
     p.xt = a.take<float>(mc); p.avg = a.take<float>(mc); p.col = a.take<float>(mc); p.edge = a.take<float>(mc);
-    p.pool = a.take<float>((size_t)B * 64 * 1024); p.pg1 = a.take<float>((size_t)B * 64 * 256);
+    p.pool = a.take<float>((size_t)B * 85 * 1024); p.pg1 = a.take<float>((size_t)B * 85 * 256);   // all four scales side by side
     p.pool8 = a.take<float>((size_t)B * 64 * 1024);
     p.pg2 = a.take<float>((size_t)B * 85 * 1024);   // the four pooled gate maps (1 + 4 + 16 + 64 positions) back to back
   }
@@ -564,19 +564,32 @@ void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
   const int scales[4] = {1, 2, 4, 8};
   const bool one_pass = pool8_supported(H, W, C);   // all four scales from one read of x
   if (one_pass) launch_pool8_sums(p.hB, C, p.pool8, B, H, W, C, s);
-  size_t goff = 0;
+  // the four pooled gate maps (avif_inference.py:227-234): each scale has its own two 1x1 layers on an S x S map -- tiny,
+  // latency-bound GEMMs, so the four first layers go out as ONE grouped launch and the four second layers as another
+  IGemm l1[4], l2[4];
+  size_t goff = 0, poff = 0, hoff = 0;
   for (int i = 0; i < 4; ++i) {
     const int S = scales[i];
-    if (one_pass) launch_pool_from8(p.pool8, p.pool, C, B, H, W, C, S, s);
-    else launch_adaptive_avgpool(p.hB, C, p.pool, C, B, H, W, C, S, s);
+    float* pooled = p.pool + poff;
+    float* hidden = p.pg1 + hoff;
+    if (one_pass) launch_pool_from8(p.pool8, pooled, C, B, H, W, C, S, s);
+    else launch_adaptive_avgpool(p.hB, C, pooled, C, B, H, W, C, S, s);
     IGemm g; g.B = B; g.H = S; g.W = S;
-    IGemm a = g; a.A = p.pool; a.lda = C; a.epi_act = ACT_RELU; a.out = p.pg1; a.ldo = C / 4;
-    conv(bw.ms1[i], a, s);
+    IGemm a = g; a.A = pooled; a.lda = C; a.epi_act = ACT_RELU; a.out = hidden; a.ldo = C / 4;
+    const ConvW& w1 = bw.ms1[i];
+    a.Wt = w1.w; a.Wt16 = w1.w16; a.bias = w1.b; a.Cout = w1.cout; a.Cin = w1.cinp; a.taps = w1.taps;
+    l1[i] = a;
     // the gate maps stay at S x S; F.interpolate(size=x.shape[-2:]) + the average happen inside avif_combine_k
-    IGemm b = g; b.A = p.pg1; b.lda = C / 4; b.epi_act = ACT_SIGMOID; b.out = p.pg2 + goff; b.ldo = C;
-    conv(bw.ms3[i], b, s);
+    IGemm b = g; b.A = hidden; b.lda = C / 4; b.epi_act = ACT_SIGMOID; b.out = p.pg2 + goff; b.ldo = C;
+    const ConvW& w3 = bw.ms3[i];
+    b.Wt = w3.w; b.Wt16 = w3.w16; b.bias = w3.b; b.Cout = w3.cout; b.Cin = w3.cinp; b.taps = w3.taps;
+    l2[i] = b;
     goff += (size_t)B * S * S * C;
+    poff += (size_t)B * S * S * C;
+    hoff += (size_t)B * S * S * (C / 4);
   }
+  launch_igemm_group(l1, 4, s);
+  launch_igemm_group(l2, 4, s);
   IGemm g; g.B = B; g.H = H; g.W = W;
   if (use_gemm16()) {   // colour + edge gates on the bf16 copy of x (plan_.hB16, refreshed by out_proj)
     IGemm c0 = g; c0.A16 = p.hB16; c0.lda16 = C; c0.epi_act = ACT_RELU; c0.out16 = p.hid16; c0.ldo16 = C;
