@@ -96,3 +96,26 @@ def test_avif_worker_process_pool_matches_in_process_codec(monkeypatch):
     assert np.array_equal(again, codec.roundtrip_u8(u8[:4], 40, "avif"))
     assert np.array_equal(pooled[0], codec._one(u8[0], 10, "avif"))
     codec._shutdown_procs()
+
+
+def test_bench_reads_roofline_traffic_from_the_committed_profile():
+    """bench.py's roofline.traffic is not a literal: it comes from profiles/*traffic*.json (tools/pmc_summary.py --json)
+    together with its provenance; an unknown workload has no traffic figure."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec_ = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(bench)
+    val, src = bench.committed_traffic("jpeg_bf16_256_B16_all")
+    assert val and val > 1e8 and src["file"].startswith("profiles/") and "bench.py" in src["command"] and "flash_bf16" in src["kernel"]
+    assert bench.committed_traffic("jpeg_bf16_64_B2_all") == (None, None)
+    # algorithmic bytes of that launch (Q + packed K/V + bf16 output, B=16, 65 536 tokens, 4 heads of 16): the measured
+    # traffic must be at least that and, with K/V re-streamed per workgroup generation, a small multiple of it
+    algo = 16 * 65536 * 64 * 2 * 2 + 16 * 4 * 2048 * 2112
+    assert algo <= val < 6 * algo
+
+
+def test_packed_blob_header_fields():
+    from ddpm_image_restoration_amd import model
+    assert model.PACKED_MAGIC == b"DDPMIRW\x00" and len(model.PACKED_MAGIC) == 8
