@@ -55,6 +55,22 @@ def test_forward_golden_64_and_nonsquare(name, arch, golden, models):
 
 
 @pytest.mark.parametrize("name,arch", ARCHS)
+def test_forward_second_weight_seed(name, arch, golden, synth_state):
+    """An independent set of reference outputs (weights of synth seed 1, other images, t near 0 and 1, compression_level
+    != t, a 64 x 32 image; tests/golden/make_golden_seed1.py): fp32 within 1e-3, bf16 mode within its budget."""
+    import torch
+    from ddpm_image_restoration_amd.model import MODEL_BY_ARCH
+    g = golden("seed1_fwd")
+    for dtype, tol_max, tol_mean in (("f32", TOL, TOL), ("bf16", 2e-2, 2e-3)):
+        m = MODEL_BY_ARCH[arch](device=torch.device("cuda", 0), dtype=dtype)
+        m.load_state_dict(synth_state(arch, 1))
+        for xs, ts, cls, ys in ((name + "_x", name + "_t", name + "_cl", name + "_y"), (name + "_x2", name + "_t2", name + "_t2", name + "_y2")):
+            e = np.abs(m(tt(g[xs]), tt(g[ts]), tt(g[cls])).cpu().numpy() - g[ys])
+            assert e.max() < tol_max and e.mean() < tol_mean, (dtype, xs, e.max(), e.mean())
+        del m
+
+
+@pytest.mark.parametrize("name,arch", ARCHS)
 def test_forward_bf16_mode(name, arch, golden, models):
     """dtype='bf16': matrix-core contractions on bf16 operands, fp32 accumulation / statistics / storage.
     Tolerance per SURVEY.md H2: teacher-forced x_theta within 2e-2 of the fp32 reference."""
