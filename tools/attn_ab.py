@@ -3,7 +3,9 @@ import sys, os, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # the variant is read once per process (static), so each variant runs in a child; rounds interleave children
 variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "5", "7", "8", "9"]
-code = "import os,sys; sys.path.insert(0,'.'); from ddpm_image_restoration_amd import ops; print(min(ops.attention_time(4,65536,64,4,1,3) for _ in range(2)))"
+B = int(os.environ.get("AB_BATCH", "4"))
+HEADS = int(os.environ.get("AB_HEADS", "4"))
+code = f"import os,sys; sys.path.insert(0,'.'); from ddpm_image_restoration_amd import ops; print(min(ops.attention_time({B},65536,64,{HEADS},1,3) for _ in range(2)))"
 res = {v: [] for v in variants}
 for rnd in range(3):
     for v in variants:

@@ -98,6 +98,25 @@ for arch in (0, 1, 2):
             d = np.concatenate(d_all); p32 = np.concatenate(p_all)
             print(nm, f"R={R} N={d.size}: restored f32 mean {p32.mean():.4f} dB; bf16-f32 mean {d.mean():+.5f} dB, std {d.std():.4f}, "
                   f"|d| max {np.abs(d).max():.4f}, p99 {np.percentile(np.abs(d), 99):.4f}; wall {time.time() - t0:.1f} s", flush=True)
+    if "psnr256" in what and arch in (0, 1):
+        # the benchmarked size: 16 images at 256x256, q10, the harness' step rule, fp32 parity mode vs bf16 (and fp8) mode
+        import time
+        R, bs, qq = 256, 16, 10
+        x0 = synth.synth_images(bs, R, seed=777)
+        y = harness.COMPRESS[arch](torch.from_numpy(x0), qq).cuda()
+        st = harness.steps_for_quality(arch, qq)
+        res = {}
+        for mode, mm in (("f32", m32), ("bf16", m16), ("fp8", model(arch, dtype="fp8"))):
+            t0 = time.time()
+            res[mode] = SAMPLER_BY_ARCH[arch](mm).sample(y, qq, steps=st, seed=3).cpu().numpy()
+            print(nm, f"R=256 {mode}: {st} steps in {time.time() - t0:.1f} s", flush=True)
+        p32 = psnr_each(res["f32"], x0)
+        pc = psnr_each(y.cpu().numpy(), x0)
+        for mode in ("bf16", "fp8"):
+            d = psnr_each(res[mode], x0) - p32
+            print(nm, f"R=256 N={bs} q={qq} steps={st}: compressed {pc.mean():.4f} dB, restored f32 {p32.mean():.4f} dB; {mode}-f32 mean {d.mean():+.5f} dB, "
+                  f"std {d.std():.4f}, |d| max {np.abs(d).max():.4f}; pixels: max |diff| {np.abs(res[mode] - res['f32']).max():.3f}, "
+                  f"mean {np.abs(res[mode] - res['f32']).mean():.5f}", flush=True)
     del m32, m16
     torch.cuda.empty_cache()
 
