@@ -660,3 +660,21 @@ def test_forward_sizes_with_ragged_levels(H, W, models):
         from ddpm_image_restoration_amd import synth as S
         ref = O.Model(spec.ARCH_JPEG, S.synth_state_dict(spec.ARCH_JPEG, 0)).forward(x, t, t)
         assert np.abs(y32.cpu().numpy() - ref).max() < TOL
+
+
+@pytest.mark.parametrize("name,arch", ARCHS)
+def test_large_nonsquare_forward_bf16_tracks_fp32(name, arch, models):
+    """192 x 320 (61 440 tokens at level 0: not a power of two, 120 query blocks of 512, rows of unequal length at every
+    level): the no-running-max attention kernel, the fused qkv packing and the DMA GEMMs against the exact-fp32 path of the
+    same library (itself pinned by the oracle at every size the oracle can run)."""
+    import torch
+    x = synth.synth_images(2, 320, seed=71)[:, :, :192, :].copy()
+    t = np.array([0.8, 0.15], np.float32)
+    y32 = models(arch)(tt(x), tt(t), tt(t))
+    y16 = models(arch, dtype="bf16")(tt(x), tt(t), tt(t))
+    e = (y16 - y32).abs()
+    print(f"{name} 192x320: bf16 vs fp32 max {float(e.max()):.2e} mean {float(e.mean()):.2e}")
+    assert torch.isfinite(y16).all() and float(e.max()) < 2e-2 and float(e.mean()) < 2e-3, (float(e.max()), float(e.mean()))
+    # and each image comes out as it does alone (batch 2 -> 1 changes the attention grid and every GEMM's tiling)
+    y1 = models(arch)(tt(x[1:]), tt(t[1:]), tt(t[1:]))
+    assert torch.equal(y1, y32[1:])
