@@ -195,7 +195,8 @@ class Context {
   struct ProfSpan { hipEvent_t a, b; int cls; double flops; };
   std::vector<ProfSpan> prof_spans_;
   std::vector<hipEvent_t> prof_pool_;
-  bool prof_on_ = false;
+  bool prof_on_ = false, prof_open_ = false;
+  int prof_detail_ = 0;             // 1 = forward + full-resolution attention spans, 2 = every attention launch
   double prof_ms_[3] = {0, 0, 0}; int64_t prof_n_[3] = {0, 0, 0}; double prof_flops_[3] = {0, 0, 0};
   hipEvent_t prof_event();
   void prof_begin(int cls, double flops, hipStream_t s);

@@ -338,6 +338,69 @@ __global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_k(const f
   }
 }
 
+// The common case of the pass above -- whole blocks (H, W multiples of BS), out = T X T^T unmixed, at most one unmasked
+// bf16 copy -- without the generality: X is dead once T X exists, no bounds or mask tests.  The general kernel keeps X live
+// for the runtime mix and carries the mask logic: 206 VGPRs / 2 waves per SIMD at BS = 8 and 208 us for the level-0 tensor
+// (B = 16, 256 x 256 x 64) against 119 us for this mapping stand-alone (tools/micro/dct_store.hip, 5.6 TB/s; wider
+// per-thread accesses -- two channels per thread, an LDS-staged patch with 16-byte I/O -- measured SLOWER there).
+template <int BS, bool PC, bool O16, bool MIX = false>
+__global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_fast_k(const float* __restrict__ in, int ldi, float* __restrict__ out,
+                                                                             int ldo, int B, int H, int W, int C,
+                                                                             const float* __restrict__ mats, __bf16* __restrict__ o16,
+                                                                             float mix_in, float mix_t) {
+  __shared__ float Ts[BS * BS];
+  if (!PC) {
+    for (int i = threadIdx.x; i < BS * BS; i += blockDim.x) Ts[i] = mats[i];
+    __syncthreads();
+  }
+  const int nby = H / BS, nbx = W / BS;
+  const int64_t total = (int64_t)B * nby * nbx * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int bx = (int)(p % nbx); p /= nbx;
+    const int by = (int)(p % nby);
+    const int b = (int)(p / nby);
+    const float* T = PC ? mats + (size_t)c * BS * BS : Ts;
+    const size_t base = (((size_t)b * H + by * BS) * W + bx * BS);
+    float X[BS][BS];
+#pragma unroll
+    for (int u = 0; u < BS; ++u)
+#pragma unroll
+      for (int v = 0; v < BS; ++v) X[u][v] = in[(base + (size_t)u * W + v) * ldi + c];
+    float tmp[BS][BS];
+#pragma unroll
+    for (int u = 0; u < BS; ++u) {
+      float tr[BS];
+#pragma unroll
+      for (int k = 0; k < BS; ++k) tr[k] = T[u * BS + k];
+#pragma unroll
+      for (int v = 0; v < BS; ++v) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < BS; ++k) a = fmaf(tr[k], X[k][v], a);
+        tmp[u][v] = a;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < BS; ++v) {
+      float tr[BS];
+#pragma unroll
+      for (int k = 0; k < BS; ++k) tr[k] = T[v * BS + k];
+#pragma unroll
+      for (int u = 0; u < BS; ++u) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < BS; ++k) a = fmaf(tmp[u][k], tr[k], a);
+        const size_t o = base + (size_t)u * W + v;
+        if (MIX) a = mix_in * X[u][v] + mix_t * a;       // the head's u5 + 0.1 DCT(u5) (webp_inference.py:396)
+        out[o * ldo + c] = a;
+        if (O16) o16[o * C + c] = (__bf16)a;
+      }
+    }
+  }
+}
+
 __global__ void mul4_add_k(const float* base, int ldb, const float* a, int lda, const float* b, int ldb2,
                            const float* c, int ldc, const float* d, int ldd, float* out, int ldo, int64_t M, int C4) {
   const int64_t total = M * C4;
@@ -572,6 +635,25 @@ void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B
   int64_t total = (int64_t)B * cdiv(H, bs) * cdiv(W, bs) * C;
   __bf16* l16 = reinterpret_cast<__bf16*>(low16);
   __bf16* h16 = reinterpret_cast<__bf16*>(high16);
+  if ((H % bs) == 0 && (W % bs) == 0 && !h16 && (bs == 4 || bs == 8)) {
+    auto go = [&](auto kern, int block) {
+      hipLaunchKernelGGL(kern, dim3(grid_for(total, block)), dim3(block), 0, s, in, ldi, out, ldo, B, H, W, C, mats, l16, mix_in, mix_t);
+    };
+    if (!(mix_in == 0.f && mix_t == 1.f)) {   // mixed output: the model's head only (shared matrix, no bf16 copy)
+      if (per_channel || l16) goto general;
+      if (bs == 4) go(block_transform_fast_k<4, false, false, true>, 256);
+      else go(block_transform_fast_k<8, false, false, true>, 128);
+    } else if (bs == 4) {
+      if (per_channel) { if (l16) go(block_transform_fast_k<4, true, true>, 256); else go(block_transform_fast_k<4, true, false>, 256); }
+      else { if (l16) go(block_transform_fast_k<4, false, true>, 256); else go(block_transform_fast_k<4, false, false>, 256); }
+    } else {
+      if (per_channel) { if (l16) go(block_transform_fast_k<8, true, true>, 128); else go(block_transform_fast_k<8, true, false>, 128); }
+      else { if (l16) go(block_transform_fast_k<8, false, true>, 128); else go(block_transform_fast_k<8, false, false>, 128); }
+    }
+    DDPMIR_HIP_CHECK(hipGetLastError());
+    return;
+  }
+general:
   if (bs == 4)
     hipLaunchKernelGGL(block_transform_k<4>, dim3(grid_for(total)), dim3(256), 0, s, in, ldi, out, ldo, B, H, W, C,
                        mats, per_channel, mix_in, mix_t, l16, h16, low);

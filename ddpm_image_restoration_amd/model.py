@@ -173,8 +173,9 @@ class _RestorationModel:
     def weight_blob_bytes(self) -> int:
         return int(self._lib.ddpmir_weight_blob_bytes(self._ctx))
 
-    def profile(self, enable: bool):
-        _lib.check(self._lib, self._ctx, self._lib.ddpmir_profile_enable(self._ctx, int(enable)), "profile_enable")
+    def profile(self, enable, detail: bool = False):
+        """HIP-event spans: forwards + full-resolution attention launches; detail=True brackets all 13 attention launches."""
+        _lib.check(self._lib, self._ctx, self._lib.ddpmir_profile_enable(self._ctx, (2 if detail else 1) if enable else 0), "profile_enable")
 
     def profile_read(self, cls: str):
         """(device ms, launches, algorithmic FLOPs) accumulated for a kernel class since profile(True)."""

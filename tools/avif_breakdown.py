@@ -10,7 +10,7 @@ for B in (8, 16):
     y = m(x, t, t); torch.cuda.synchronize()
     t0 = time.time(); y = m(x, t, t); torch.cuda.synchronize()
     print(f"AVIF forward B={B}: {(time.time()-t0)*1e3:.1f} ms", flush=True)
-    m.profile(True); y = m(x, t, t); torch.cuda.synchronize()
+    m.profile(True, detail=True); y = m(x, t, t); torch.cuda.synchronize()
     for cls in ("attention_l0", "attention", "forward"):
         ms, n, fl = m.profile_read(cls); print("  ", cls, round(ms, 2), n)
     m.profile(False)

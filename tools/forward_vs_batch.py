@@ -12,7 +12,7 @@ for B in (1, 2, 4, 8, 16, 32):
     t = torch.full((B,), 0.5, device="cuda")
     for _ in range(2): m(x, t, t)
     torch.cuda.synchronize()
-    m.profile(True)
+    m.profile(True, detail=True)
     for _ in range(5): m(x, t, t)
     torch.cuda.synchronize()
     m.profile(False)
