@@ -415,6 +415,46 @@ int ddpmir_op_block_transform(const float* x, int B, int H, int W, int C, int bs
   });
 }
 
+int ddpmir_op_freq_gates_bf16(const float* x, int B, int H, int W, int C, int bs, int low, const float* dct, const float* w1,
+                              const float* b1, const float* w2, const float* b2, const float* boost, int fused, float* out) {
+  return guarded([&] {
+    if (C % 64) throw std::runtime_error("freq_gates: C must be a multiple of 64");
+    Dev d;
+    const size_t M = (size_t)B * H * W;
+    auto bf = [](float f) {
+      unsigned int u;
+      memcpy(&u, &f, 4);
+      return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    };
+    std::vector<unsigned short> w1h((size_t)C * C), w2h((size_t)2 * C * C);
+    for (size_t i = 0; i < w1h.size(); ++i) w1h[i] = bf(w1[i]);
+    for (size_t i = 0; i < w2h.size(); ++i) w2h[i] = bf(w2[i]);
+    const float* xd_in = d.up(x, M * C);
+    const unsigned short* W1 = d.up(w1h.data(), w1h.size());
+    const unsigned short* W2 = d.up(w2h.data(), w2h.size());
+    const float *B1 = d.up(b1, C), *B2 = d.up(b2, 2 * C), *BO = d.up(boost, B), *T = d.up(dct, (size_t)bs * bs);
+    unsigned short* S16 = d.alloc<unsigned short>(M * C);
+    if (fused) {
+      launch_freq_gate_fused(xd_in, T, W1, B1, W2, B2, BO, S16, B, H, W, C, bs, low, nullptr);
+    } else {   // the three-kernel path of Context::run_block16
+      float* xd = d.alloc<float>(M * C);
+      unsigned short* xdl16 = d.alloc<unsigned short>(M * C);
+      unsigned short* hid16 = d.alloc<unsigned short>(M * C);
+      launch_block_transform(xd_in, C, xd, C, B, H, W, C, bs, T, 0, 0.f, 1.f, nullptr, xdl16, nullptr, low);
+      IGemm g; g.B = B; g.H = H; g.W = W; g.bs = bs; g.low = low; g.taps = 1;
+      g.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); g.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); g.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
+      IGemm a = g; a.A16 = xdl16; a.lda16 = C; a.Wt16 = W1; a.bias = B1; a.Cin = C; a.Cout = C; a.epi_act = ACT_LRELU; a.out16 = hid16; a.ldo16 = C;
+      launch_gemm16(a, nullptr);
+      IGemm e = g; e.A16 = hid16; e.lda16 = C; e.Wt16 = W2; e.bias = B2; e.Cin = C; e.Cout = 2 * C; e.epi_act = ACT_SIGMOID; e.mul = xd; e.ldmul = C;
+      e.sel_C = C; e.rowscale = BO; e.res = xd_in; e.ldres = C; e.out16 = S16; e.ldo16 = C;
+      launch_gemm16(e, nullptr);
+    }
+    std::vector<unsigned short> h(M * C);
+    d.down(h.data(), S16, M * C);
+    for (size_t i = 0; i < h.size(); ++i) { unsigned int u = (unsigned int)h[i] << 16; memcpy(&out[i], &u, 4); }
+  });
+}
+
 int ddpmir_op_maxpool2(const float* x, int B, int H, int W, int C, float* out) {
   return guarded([&] {
     Dev d;

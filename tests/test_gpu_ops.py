@@ -472,3 +472,38 @@ def test_attention_bf16_no_max_and_general_kernels(ops):
         for b in range(B):
             e = np.abs(got[b] - ref[b])
             assert e.max() < 3e-2 and e.mean() < 2e-3, (heads, b, e.max(), e.mean())
+
+
+@pytest.mark.parametrize("B,H,W,bs,low", [(2, 16, 32, 8, 4), (3, 32, 32, 4, 3), (1, 64, 64, 8, 4), (2, 8, 16, 4, 3)])
+def test_frequency_block_one_pass_kernel(ops, B, H, W, bs, low):
+    """DCT + both gate layers + S = x + g * DCT(x) in one kernel (freq_fused.hip, the C = 64 blocks) against the three
+    kernels it replaces (bit for bit: same FMA / MFMA order, same bf16 roundings) and against a float64 restatement of
+    webp_inference.py:231-270 on the bf16-rounded operands."""
+    from ddpm_image_restoration_amd.synth import dct_matrix
+    C = 64
+    x = rnd(B, C, H, W, seed=50)
+    D = dct_matrix(bs)
+    w1 = rnd(C, C, seed=51, scale=0.2)
+    b1 = rnd(C, seed=52, scale=0.3)
+    w2 = rnd(2 * C, C, seed=53, scale=0.3)
+    w2[:C, C // 2:] = 0; w2[C:, :C // 2] = 0
+    b2 = rnd(2 * C, seed=54, scale=0.3)
+    boost = np.abs(rnd(B, seed=55)) + 0.5
+    fused = ops.freq_gates_bf16(nhwc(x), D, w1, b1, w2, b2, boost, low, fused=True)
+    three = ops.freq_gates_bf16(nhwc(x), D, w1, b1, w2, b2, boost, low, fused=False)
+    ndiff = int((fused != three).sum())
+    print(f"fused vs three kernels: {ndiff} of {fused.size} bf16 values differ, max |d| {np.abs(fused - three).max():.2e}")
+    assert ndiff == 0
+
+    def bf(z):
+        u = np.ascontiguousarray(z, dtype=np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    xd = O.blockwise_transform(x, D)
+    hid = O.conv2d(bf(xd), bf(w1)[:, :, None, None], b1, 0)
+    hid = np.where(hid > 0, hid, 0.2 * hid).astype(np.float32)
+    z = O.conv2d(bf(hid), bf(w2)[:, :, None, None], b2, 0).astype(np.float64)
+    sig = 1 / (1 + np.exp(-z))
+    m = O.low_mask(H, W, bs, low)[None, None]
+    ref = x + xd * np.where(m > 0, sig[:, :C], sig[:, C:] * boost[:, None, None, None])
+    err = np.abs(nchw(fused) - ref)
+    assert err.max() < 4e-2 and err.mean() < 2e-3, (err.max(), err.mean())     # the final bf16 rounding of S (|S| up to ~4)
