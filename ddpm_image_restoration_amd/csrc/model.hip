@@ -705,7 +705,7 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
     launch_gn_apply16(p.S, C, B, HW, C, nullptr, nullptr, ACT_NONE, co_f8 ? nullptr : p.S16, C, nullptr, 0, s, nullptr, 0,
                       co_f8 ? p.S8 : nullptr, C);
   } else if (!split_gates && !co_f8 && !exp_switch("DDPMIR_NO_FREQ_FUSE") && freq_gate_fused_supported(B, H, W, C, k.dct_block)) {
-    // full-resolution blocks (C = 64): DCT, both gate layers and S = x + g * xd in one pass over x (freq_fused.hip)
+    // 64- and 128-channel blocks: DCT, both gate layers and S = x + g * xd in one pass over x (freq_fused.hip)
     launch_freq_gate_fused(p.hB, bw.dct, bw.fg1.w16, bw.fg1.b, bw.fg2.w16, bw.fg2.b, p.boost, p.S16, B, H, W, C, k.dct_block,
                            k.low_size, s);
   } else if (!split_gates) {

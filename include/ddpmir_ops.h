@@ -63,7 +63,7 @@ int ddpmir_op_block_transform(const float* x, int B, int H, int W, int C, int bs
 
 /* frequency block of the DCT families in bf16 mode (webp_inference.py:231-270): S = x + gate(DCT(x)) * DCT(x) as bf16 values;
  * w1 [C][C] = both gates' first layers stacked, w2 [2C][C] block-diagonal second layers (model.hip put_gate_pair);
- * fused = 0: DCT kernel + two DMA GEMMs, fused = 1: the one-pass kernel (C = 64 only) */
+ * fused = 0: DCT kernel + two DMA GEMMs, fused = 1: the one-pass kernel (C = 64 or 128) */
 int ddpmir_op_freq_gates_bf16(const float* x, int B, int H, int W, int C, int bs, int low, const float* dct, const float* w1,
                               const float* b1, const float* w2, const float* b2, const float* boost, int fused, float* out);
 int ddpmir_op_maxpool2(const float* x, int B, int H, int W, int C, float* out);        /* webp_inference.py:342 */

@@ -474,13 +474,13 @@ def test_attention_bf16_no_max_and_general_kernels(ops):
             assert e.max() < 3e-2 and e.mean() < 2e-3, (heads, b, e.max(), e.mean())
 
 
-@pytest.mark.parametrize("B,H,W,bs,low", [(2, 16, 32, 8, 4), (3, 32, 32, 4, 3), (1, 64, 64, 8, 4), (2, 8, 16, 4, 3)])
-def test_frequency_block_one_pass_kernel(ops, B, H, W, bs, low):
-    """DCT + both gate layers + S = x + g * DCT(x) in one kernel (freq_fused.hip, the C = 64 blocks) against the three
+@pytest.mark.parametrize("B,H,W,bs,low,C", [(2, 16, 32, 8, 4, 64), (3, 32, 32, 4, 3, 64), (1, 64, 64, 8, 4, 64), (2, 8, 16, 4, 3, 64),
+                                             (2, 16, 24, 8, 4, 128), (3, 16, 16, 4, 3, 128), (1, 32, 64, 8, 4, 128)])
+def test_frequency_block_one_pass_kernel(ops, B, H, W, bs, low, C):
+    """DCT + both gate layers + S = x + g * DCT(x) in one kernel (freq_fused.hip, the 64- and 128-channel blocks) against the three
     kernels it replaces (bit for bit: same FMA / MFMA order, same bf16 roundings) and against a float64 restatement of
     webp_inference.py:231-270 on the bf16-rounded operands."""
     from ddpm_image_restoration_amd.synth import dct_matrix
-    C = 64
     x = rnd(B, C, H, W, seed=50)
     D = dct_matrix(bs)
     w1 = rnd(C, C, seed=51, scale=0.2)
