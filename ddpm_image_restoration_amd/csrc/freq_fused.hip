@@ -46,12 +46,16 @@ struct FGeom {
   static constexpr int KK = C / 32;                    // k-steps of one gate's second layer (it reads half the hidden units)
 };
 
-template <int BS, int C>
+// OP = true: x is not read as it stands but formed first as  x = W_o att + b_o + x_in  (the attention's output projection with
+// its residual, webp_inference.py:317-321: MultiheadAttention.out_proj and h + attn) -- one more GEMM on the tile instead of
+// a separate pass that writes x (fp32) only for this kernel to read it back.
+template <int BS, int C, bool OP>
 __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restrict__ x, const float* __restrict__ dct,
                                                             const __bf16* __restrict__ w1, const float* __restrict__ b1,
                                                             const __bf16* __restrict__ w2, const float* __restrict__ b2,
                                                             const float* __restrict__ boost, __bf16* __restrict__ S16, int H, int W,
-                                                            int low) {
+                                                            int low, const __bf16* __restrict__ att16, const __bf16* __restrict__ wo,
+                                                            const float* __restrict__ bo) {
   using G = FGeom<C>;
   constexpr int BB = BS * BS, NBLK = G::PT / BB, XS = G::XS, ROWB = G::ROWB, CPR = G::CPR, RSH = G::RSH, KS = G::KS, KK = G::KK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -91,6 +95,51 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
   if (tid < BB) Ts[tid] = dct[tid];
   if (tid < C) B1s[tid] = b1[tid];
   if (tid < 2 * C) B2s[tid] = b2[tid];
+  const int lr = lane & 31, lh = lane >> 5;
+  const int arow = row0 + lr, a_key = (arow >> RSH) & (CPR - 1);
+  const unsigned char* arow_p = A16 + arow * ROWB;
+  if constexpr (OP) {
+    // attention output rows -> operand rows (16-byte chunks, swizzled), then x = W_o att + b_o + x_in in the fp32 patch
+    if (tid < C) B2s[2 * C + tid] = bo[tid];
+    constexpr int CH = G::PT * CPR / 256;              // chunks per thread: 4
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int q = i * 256 + tid, row = q / CPR, p = q % CPR;
+      *reinterpret_cast<bf16x8*>(A16 + row * ROWB + ((p ^ ((row >> RSH) & (CPR - 1))) << 4)) =
+          *reinterpret_cast<const bf16x8*>(att16 + pix(row) * C + 8 * p);
+    }
+    __syncthreads();
+    f32x16 acc0[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[nt][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(arow_p + (((2 * ks + lh) ^ a_key) << 4));
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(wo + (size_t)(col0 + nt * 32 + lr) * C + (2 * ks + lh) * 8);
+        acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc0[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = col0 + nt * 32 + lr;
+      const float bc = B2s[2 * C + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float* px = X32 + (row0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XS + col;
+        float v = acc0[nt][r];
+        v += bc;
+        v += *px;
+        *px = v;
+      }
+    }
+    __syncthreads();     // x is complete; every wave is done with the operand rows
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xreg[i] = *reinterpret_cast<const float4*>(X32 + (row0 + 4 * i + rsub) * XS + col0 + 4 * c4);
+  }
   __syncthreads();
 
   // ---- phase B: block DCT in place (fp32) + bf16 operand rows.  Same FMA order as block_transform_fast_k.
@@ -176,9 +225,6 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
   __syncthreads();
 
   // ---- phase C: hid = lrelu(W1 xd16 + b1); the hidden layer then overwrites the operand rows
-  const int lr = lane & 31, lh = lane >> 5;
-  const int arow = row0 + lr, a_key = (arow >> RSH) & (CPR - 1);
-  const unsigned char* arow_p = A16 + arow * ROWB;
   f32x16 acc1[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
@@ -258,19 +304,32 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
   }
 }
 
-template <int BS, int C>
+template <int BS, int C, bool OP>
 void launch_t(const float* x, const float* dct, const void* w1, const float* b1, const void* w2, const float* b2, const float* boost,
-              void* S16, int B, int H, int W, int low, hipStream_t s) {
+              void* S16, int B, int H, int W, int low, const void* att16, const void* wo, const float* bo, hipStream_t s) {
   using G = FGeom<C>;
-  constexpr int LDS = G::X32_BYTES + G::A16_BYTES + (BS * BS + C + 2 * C) * 4;
+  constexpr int LDS = G::X32_BYTES + G::A16_BYTES + (BS * BS + C + 2 * C + (OP ? C : 0)) * 4;
   static PerDeviceOnce attr;
   attr.run([] {
-    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&freq_gate_fused_k<BS, C>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&freq_gate_fused_k<BS, C, OP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   });
   const int64_t tiles = (int64_t)B * (H / BS) * (W / BS) / (G::PT / (BS * BS));
-  hipLaunchKernelGGL((freq_gate_fused_k<BS, C>), dim3((unsigned)tiles), dim3(256), LDS, s, x, dct, reinterpret_cast<const __bf16*>(w1), b1,
-                     reinterpret_cast<const __bf16*>(w2), b2, boost, reinterpret_cast<__bf16*>(S16), H, W, low);
+  hipLaunchKernelGGL((freq_gate_fused_k<BS, C, OP>), dim3((unsigned)tiles), dim3(256), LDS, s, x, dct, reinterpret_cast<const __bf16*>(w1), b1,
+                     reinterpret_cast<const __bf16*>(w2), b2, boost, reinterpret_cast<__bf16*>(S16), H, W, low,
+                     reinterpret_cast<const __bf16*>(att16), reinterpret_cast<const __bf16*>(wo), bo);
   DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+template <bool OP>
+void launch_op(const float* x, const float* dct, const void* w1, const float* b1, const void* w2, const float* b2, const float* boost,
+               void* S16, int B, int H, int W, int C, int bs, int low, const void* att16, const void* wo, const float* bo, hipStream_t s) {
+  if (C == 64) {
+    if (bs == 8) launch_t<8, 64, OP>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, att16, wo, bo, s);
+    else launch_t<4, 64, OP>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, att16, wo, bo, s);
+  } else {
+    if (bs == 8) launch_t<8, 128, OP>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, att16, wo, bo, s);
+    else launch_t<4, 128, OP>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, att16, wo, bo, s);
+  }
 }
 
 }  // namespace
@@ -281,15 +340,16 @@ bool freq_gate_fused_supported(int B, int H, int W, int C, int bs) {
   return nblk >= 1 && (per_image % nblk) == 0;          // a tile never straddles two images
 }
 
+// att16 != nullptr: x is formed in the kernel as W_o att16 + b_o + x (the output projection of the block's attention)
 void launch_freq_gate_fused(const float* x, const float* dct, const void* w1, const float* b1, const void* w2, const float* b2,
-                            const float* boost, void* S16, int B, int H, int W, int C, int bs, int low, hipStream_t s) {
+                            const float* boost, void* S16, int B, int H, int W, int C, int bs, int low, hipStream_t s,
+                            const void* att16, const void* wo, const float* bo) {
   if (!freq_gate_fused_supported(B, H, W, C, bs)) throw std::runtime_error("fused frequency gates: unsupported shape");
-  if (C == 64) {
-    if (bs == 8) launch_t<8, 64>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, s);
-    else launch_t<4, 64>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, s);
+  if (att16) {
+    if (!wo || !bo) throw std::runtime_error("fused frequency gates: output projection needs its weight and bias");
+    launch_op<true>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, C, bs, low, att16, wo, bo, s);
   } else {
-    if (bs == 8) launch_t<8, 128>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, s);
-    else launch_t<4, 128>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, s);
+    launch_op<false>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, C, bs, low, nullptr, nullptr, nullptr, s);
   }
 }
 

@@ -121,8 +121,10 @@ void launch_pool_from8(const float* sums, float* out, int ldo, int B, int H, int
 // low16/high16 (optional): bf16 copies of the result masked to the low / high in-block frequencies [B*H*W][C]
 // DCT + both frequency gates + S = x + g * xd in one pass (freq_fused.hip; bf16 mode, C = 64, whole bs x bs blocks)
 bool freq_gate_fused_supported(int B, int H, int W, int C, int bs);
+// (att16 != null: x := W_o att16 + b_o + x is formed inside, i.e. the attention's out_proj + residual rides along)
 void launch_freq_gate_fused(const float* x, const float* dct, const void* w1, const float* b1, const void* w2, const float* b2,
-                            const float* boost, void* S16, int B, int H, int W, int C, int bs, int low, hipStream_t s);
+                            const float* boost, void* S16, int B, int H, int W, int C, int bs, int low, hipStream_t s,
+                            const void* att16 = nullptr, const void* wo = nullptr, const float* bo = nullptr);
 void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int bs,
                             const float* mats, int per_channel, float mix_in, float mix_t, hipStream_t s,
                             void* low16 = nullptr, void* high16 = nullptr, int low = 0);

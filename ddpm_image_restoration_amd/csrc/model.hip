@@ -667,6 +667,9 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   launch_gn_apply16(p.hA, C, B, HW, C, p.sc2, p.sh2, ACT_GELU, c2_f8 ? nullptr : p.a16, C, nullptr, 0, s, nullptr, 0,
                     c2_f8 ? p.a8 : nullptr, C);
   const bool attn = bw.level >= cfg.attn_min_level;
+  // 64- and 128-channel blocks of the DCT families: DCT, both gate layers and S = x + g * xd run as one pass over x
+  const bool fuse_freq = cfg.arch != DDPMIR_ARCH_AVIF && !exp_switch("DDPMIR_SPLIT_GATES") && !co_f8 && !exp_switch("DDPMIR_NO_FREQ_FUSE") &&
+                         freq_gate_fused_supported(B, H, W, C, k.dct_block);
   IGemm c2 = g; c2.A16 = p.a16; c2.lda16 = C; c2.out = p.hB; c2.ldo = C;
   if (attn) { c2.out16 = p.hB16; c2.ldo16 = C; }
   if (c2_f8) { c2.A16 = p.a8; conv8(bw.conv2, c2, s); }
@@ -692,9 +695,13 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
       launch_gn_apply16(p.att, C, B, HW, C, nullptr, nullptr, ACT_NONE, p.att16, C, nullptr, 0, s);
     }
     prof_end(s);
-    IGemm o = g; o.A16 = p.att16; o.lda16 = C; o.res = p.hB; o.ldres = C; o.out = p.hB; o.ldo = C;
-    if (cfg.arch == DDPMIR_ARCH_AVIF) { o.out16 = p.hB16; o.ldo16 = C; }   // the colour / edge gates read x as bf16
-    conv16(bw.out_proj, o, s);
+    // 64-channel blocks: the output projection and its residual are formed inside the frequency-block kernel (level 0:
+    // 135 + 165 us -> 231 us); at 128 channels the extra GEMM on 64-pixel tiles costs more than the pass it saves (176 vs 150 us)
+    if (!(fuse_freq && C == 64)) {
+      IGemm o = g; o.A16 = p.att16; o.lda16 = C; o.res = p.hB; o.ldres = C; o.out = p.hB; o.ldo = C;
+      if (cfg.arch == DDPMIR_ARCH_AVIF) { o.out16 = p.hB16; o.ldo16 = C; }   // the colour / edge gates read x as bf16
+      conv16(bw.out_proj, o, s);
+    }
   } else if (cfg.arch == DDPMIR_ARCH_AVIF) {
     launch_gn_apply16(p.hB, C, B, HW, C, nullptr, nullptr, ACT_NONE, p.hB16, C, nullptr, 0, s);
   }
@@ -704,10 +711,10 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
     freq_avif(bw, H, W, s);                                            // -> plan_.S (fp32)
     launch_gn_apply16(p.S, C, B, HW, C, nullptr, nullptr, ACT_NONE, co_f8 ? nullptr : p.S16, C, nullptr, 0, s, nullptr, 0,
                       co_f8 ? p.S8 : nullptr, C);
-  } else if (!split_gates && !co_f8 && !exp_switch("DDPMIR_NO_FREQ_FUSE") && freq_gate_fused_supported(B, H, W, C, k.dct_block)) {
-    // 64- and 128-channel blocks: DCT, both gate layers and S = x + g * xd in one pass over x (freq_fused.hip)
+  } else if (fuse_freq) {
+    // (freq_fused.hip; with attention in the block, x = out_proj(att) + x is formed there too)
     launch_freq_gate_fused(p.hB, bw.dct, bw.fg1.w16, bw.fg1.b, bw.fg2.w16, bw.fg2.b, p.boost, p.S16, B, H, W, C, k.dct_block,
-                           k.low_size, s);
+                           k.low_size, s, attn && C == 64 ? p.att16 : nullptr, bw.out_proj.w16, bw.out_proj.b);
   } else if (!split_gates) {
     launch_block_transform(p.hB, C, p.xd, C, B, H, W, C, k.dct_block, bw.dct, 0, 0.f, 1.f, s, p.xdl16, nullptr, k.low_size);
     IGemm a = g; a.A16 = p.xdl16; a.lda16 = C; a.epi_act = ACT_LRELU; a.out16 = p.hid16; a.ldo16 = C;

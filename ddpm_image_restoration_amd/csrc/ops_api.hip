@@ -416,7 +416,8 @@ int ddpmir_op_block_transform(const float* x, int B, int H, int W, int C, int bs
 }
 
 int ddpmir_op_freq_gates_bf16(const float* x, int B, int H, int W, int C, int bs, int low, const float* dct, const float* w1,
-                              const float* b1, const float* w2, const float* b2, const float* boost, int fused, float* out) {
+                              const float* b1, const float* w2, const float* b2, const float* boost, int fused, float* out,
+                              const float* att, const float* wo, const float* bo) {
   return guarded([&] {
     if (C % 64) throw std::runtime_error("freq_gates: C must be a multiple of 64");
     Dev d;
@@ -434,15 +435,30 @@ int ddpmir_op_freq_gates_bf16(const float* x, int B, int H, int W, int C, int bs
     const unsigned short* W2 = d.up(w2h.data(), w2h.size());
     const float *B1 = d.up(b1, C), *B2 = d.up(b2, 2 * C), *BO = d.up(boost, B), *T = d.up(dct, (size_t)bs * bs);
     unsigned short* S16 = d.alloc<unsigned short>(M * C);
+    IGemm g0; g0.B = B; g0.H = H; g0.W = W; g0.bs = bs; g0.low = low; g0.taps = 1;
+    g0.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); g0.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); g0.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
+    const unsigned short *ATT = nullptr, *WO = nullptr;
+    const float* BOo = nullptr;
+    if (att) {   // x = W_o att + b_o + x first (the attention's output projection and residual)
+      std::vector<unsigned short> ah(M * C), wh((size_t)C * C);
+      for (size_t i = 0; i < ah.size(); ++i) ah[i] = bf(att[i]);
+      for (size_t i = 0; i < wh.size(); ++i) wh[i] = bf(wo[i]);
+      ATT = d.up(ah.data(), ah.size()); WO = d.up(wh.data(), wh.size()); BOo = d.up(bo, C);
+      if (!fused) {
+        float* xo = d.alloc<float>(M * C);
+        IGemm o = g0; o.A16 = ATT; o.lda16 = C; o.Wt16 = WO; o.bias = BOo; o.Cin = C; o.Cout = C; o.res = xd_in; o.ldres = C; o.out = xo; o.ldo = C;
+        launch_gemm16(o, nullptr);
+        xd_in = xo;
+      }
+    }
     if (fused) {
-      launch_freq_gate_fused(xd_in, T, W1, B1, W2, B2, BO, S16, B, H, W, C, bs, low, nullptr);
-    } else {   // the three-kernel path of Context::run_block16
+      launch_freq_gate_fused(xd_in, T, W1, B1, W2, B2, BO, S16, B, H, W, C, bs, low, nullptr, ATT, WO, BOo);
+    } else {   // the kernels of Context::run_block16 before the fusion
       float* xd = d.alloc<float>(M * C);
       unsigned short* xdl16 = d.alloc<unsigned short>(M * C);
       unsigned short* hid16 = d.alloc<unsigned short>(M * C);
       launch_block_transform(xd_in, C, xd, C, B, H, W, C, bs, T, 0, 0.f, 1.f, nullptr, xdl16, nullptr, low);
-      IGemm g; g.B = B; g.H = H; g.W = W; g.bs = bs; g.low = low; g.taps = 1;
-      g.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); g.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); g.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
+      IGemm g = g0;
       IGemm a = g; a.A16 = xdl16; a.lda16 = C; a.Wt16 = W1; a.bias = B1; a.Cin = C; a.Cout = C; a.epi_act = ACT_LRELU; a.out16 = hid16; a.ldo16 = C;
       launch_gemm16(a, nullptr);
       IGemm e = g; e.A16 = hid16; e.lda16 = C; e.Wt16 = W2; e.bias = B2; e.Cin = C; e.Cout = 2 * C; e.epi_act = ACT_SIGMOID; e.mul = xd; e.ldmul = C;

@@ -25,7 +25,8 @@ _sigs = {
     "ddpmir_op_attention_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ddpmir_op_block_transform": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float,
                                             C.c_float, _P]),
-    "ddpmir_op_freq_gates_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "ddpmir_op_freq_gates_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P,
+                                            _P, _P, _P]),
     "ddpmir_op_maxpool2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ddpmir_op_upsample2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ddpmir_op_bilinear": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
@@ -170,14 +171,16 @@ def block_transform(x, mats, mix_in=0.0, mix_t=1.0):
     return out
 
 
-def freq_gates_bf16(x, dct, w1, b1, w2, b2, boost, low, fused=True):
-    """S = x + gate(DCT(x)) * DCT(x) of the DCT families' frequency block in bf16 mode (NHWC; bf16 values as float32)."""
+def freq_gates_bf16(x, dct, w1, b1, w2, b2, boost, low, fused=True, att=None, wo=None, bo=None):
+    """S = x + gate(DCT(x)) * DCT(x) of the DCT families' frequency block in bf16 mode (NHWC; bf16 values as float32);
+    with att / wo / bo: x := wo att + bo + x first (the block attention's output projection and residual)."""
     lib = _lib_ops()
     x, dct, w1, b1, w2, b2, boost = _f(x), _f(dct), _f(w1), _f(b1), _f(w2), _f(b2), _f(boost)
+    att, wo, bo = _f(att), _f(wo), _f(bo)
     b, h, w, c = x.shape
     out = np.empty_like(x)
     _chk(lib, lib.ddpmir_op_freq_gates_bf16(_p(x), b, h, w, c, dct.shape[-1], int(low), _p(dct), _p(w1), _p(b1), _p(w2), _p(b2),
-                                            _p(boost), int(fused), _p(out)), "op_freq_gates_bf16")
+                                            _p(boost), int(fused), _p(out), _p(att), _p(wo), _p(bo)), "op_freq_gates_bf16")
     return out
 
 

@@ -65,7 +65,9 @@ int ddpmir_op_block_transform(const float* x, int B, int H, int W, int C, int bs
  * w1 [C][C] = both gates' first layers stacked, w2 [2C][C] block-diagonal second layers (model.hip put_gate_pair);
  * fused = 0: DCT kernel + two DMA GEMMs, fused = 1: the one-pass kernel (C = 64 or 128) */
 int ddpmir_op_freq_gates_bf16(const float* x, int B, int H, int W, int C, int bs, int low, const float* dct, const float* w1,
-                              const float* b1, const float* w2, const float* b2, const float* boost, int fused, float* out);
+                              const float* b1, const float* w2, const float* b2, const float* boost, int fused, float* out,
+                              const float* att /* or NULL: x := wo att + bo + x first (attention out_proj + residual) */,
+                              const float* wo, const float* bo);
 int ddpmir_op_maxpool2(const float* x, int B, int H, int W, int C, float* out);        /* webp_inference.py:342 */
 int ddpmir_op_upsample2(const float* x, int B, int H, int W, int C, float* out);       /* webp_inference.py:389 */
 int ddpmir_op_bilinear(const float* x, int B, int Hi, int Wi, int C, int Ho, int Wo, float* out);

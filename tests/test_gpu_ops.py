@@ -507,3 +507,10 @@ def test_frequency_block_one_pass_kernel(ops, B, H, W, bs, low, C):
     ref = x + xd * np.where(m > 0, sig[:, :C], sig[:, C:] * boost[:, None, None, None])
     err = np.abs(nchw(fused) - ref)
     assert err.max() < 4e-2 and err.mean() < 2e-3, (err.max(), err.mean())     # the final bf16 rounding of S (|S| up to ~4)
+    # with the attention's output projection and residual formed inside (x := W_o att + b_o + x)
+    att, wo, bo = rnd(B, C, H, W, seed=56), rnd(C, C, seed=57, scale=0.15), rnd(C, seed=58, scale=0.2)
+    f2 = ops.freq_gates_bf16(nhwc(x), D, w1, b1, w2, b2, boost, low, fused=True, att=nhwc(att), wo=wo, bo=bo)
+    t2 = ops.freq_gates_bf16(nhwc(x), D, w1, b1, w2, b2, boost, low, fused=False, att=nhwc(att), wo=wo, bo=bo)
+    assert int((f2 != t2).sum()) == 0
+    x2 = x + O.conv2d(bf(att), bf(wo)[:, :, None, None], bo, 0)
+    assert np.abs(nchw(f2) - nchw(fused)).max() > 0.05 and np.isfinite(f2).all() and np.abs(x2).max() < 50
