@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
   }
   const int m0 = bx * BM, n0 = by * (NT * 32);
   const int nck = (p.Cin + BKE - 1) / BKE;
-  const int nit_main = p.taps * nck;
+  const int nit_main = p.tap_pack ? (9 + CPR - 1) / CPR : p.taps * nck;
   const int nit_all = nit_main + (F8 ? 0 : (p.Cinb + BK - 1) / BK);
   const int nsplit = gridDim.z, sk = blockIdx.z;
   const int it0 = (int)((long long)nit_all * sk / nsplit), it1 = (int)((long long)nit_all * (sk + 1) / nsplit);
@@ -148,6 +148,25 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
         const bool ok = b_n[j] < p.Cout && c < p.Cinb;
         const void* g = ok ? (const void*)(W16b + (size_t)b_n[j] * p.Cinb + c) : (const void*)zero;
         __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sbase2 + A_BYTES + (j * 256 + wave * 64) * 16), 16, 0, 0);
+      }
+      return;
+    }
+    if (!F8 && p.tap_pack) {   // 8-channel 3x3 operand: chunk q of the K axis = tap q (wave-uniform branch)
+      const unsigned sb = lds0 + (itl % STAGES) * STAGE;
+#pragma unroll
+      for (int j = 0; j < AL; ++j) {
+        const int q = it * CPR + a_chunk[j];
+        const int dy = q / 3 - 1, dx = q - (q / 3) * 3 - 1;
+        const bool ok = a_ok[j] && q < 9 && (unsigned)(a_y[j] + dy) < (unsigned)p.H && (unsigned)(a_x[j] + dx) < (unsigned)p.W;
+        const void* g = ok ? (const void*)(A16 + a_off[j] + (ptrdiff_t)(dy * p.W + dx) * p.lda16) : (const void*)zero;
+        __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sb + (j * 256 + wave * 64) * 16), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < BL; ++j) {
+        const int q = it * CPR + b_chunk[j];
+        const bool ok = b_n[j] < p.Cout && q < 9;
+        const void* g = ok ? (const void*)(W16 + ((size_t)q * p.Cout + b_n[j]) * 8) : (const void*)zero;
+        __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sb + A_BYTES + (j * 256 + wave * 64) * 16), 16, 0, 0);
       }
       return;
     }
@@ -519,7 +538,8 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   });
   const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
-  const int nit = p.taps * cdiv(p.Cin, F8 ? 2 * BK : BK) + cdiv(p.Cinb, BK);
+  const bool tap_pack = !F8 && p.taps == 9 && p.Cin == 8 && p.lda16 == 8 && !p.Cinb;
+  const int nit = tap_pack ? cdiv(9, BK / 8) : p.taps * cdiv(p.Cin, F8 ? 2 * BK : BK) + cdiv(p.Cinb, BK);
   int nsplit = 1;
   const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && (p.out || p.out16 || p.out8) && !p.pk_q &&
                       !p.sel_C && !p.gn_sums && p.splitk_ws;
@@ -529,6 +549,7 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
     if (nsplit < 1) nsplit = 1;
   }
   IGemm q = p;
+  q.tap_pack = tap_pack;
   q.nmajor = gx * gy < 256;                             // few M tiles: the weight stream is what to keep inside one L2
   const dim3 grid = q.nmajor ? dim3(gy, gx, nsplit) : dim3(gx, gy, nsplit);
   hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES, F8>), grid, dim3(256), LDS, stream, q);

@@ -52,6 +52,9 @@ struct IGemm {
   // second K segment (gemm16.hip): a 1x1 operand pair appended after the taps of the first, e.g. the block's 1x1
   // shortcut conv folded into conv_out (out = W_out * S + W_sc * x + (b_out + b_sc)): saves one write + read of `out`
   const void* A16b = nullptr; int lda16b = 0; const void* Wt16b = nullptr; int Cinb = 0;
+  // gemm16.hip, set by the launcher: 3x3 conv on an 8-channel operand (the image conv): the nine taps x 8 channels are ONE
+  // K axis of 72 (a 16-byte chunk = one tap), two K stages instead of nine mostly-zero ones
+  int tap_pack = 0;
   void* pk_q = nullptr; void* pk_kv = nullptr; float* pk_kmax = nullptr; int pk_nt = 0; float pk_qscale = 0.f; int pk_D = 16;
   // split-K partial sums [nsplit][M][Cout] fp32 (gemm16.hip): written by the splits, folded in fixed order by a second
   // kernel together with bias / time bias / residual / bf16 copy -> bf16 mode is bit-reproducible (no float atomics)

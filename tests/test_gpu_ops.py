@@ -373,10 +373,11 @@ def test_randn_moments_and_shard_independence(ops):
     assert np.array_equal(a[1 << 19:], b)       # second half drawn as its own shard: same numbers@pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k", [
     (1, 12, 20, 64, 64, 3), (2, 16, 16, 128, 384, 1), (2, 16, 16, 64, 32, 1), (5, 7, 3, 36, 40, 3), (1, 6, 10, 68, 96, 1),
-    (1, 4, 4, 1024, 1024, 3), (3, 2, 2, 200, 132, 3), (1, 1, 1, 16, 8, 3), (2, 32, 32, 3, 64, 3), (1, 9, 130, 72, 128, 3)])
+    (1, 4, 4, 1024, 1024, 3), (3, 2, 2, 200, 132, 3), (1, 1, 1, 16, 8, 3), (2, 32, 32, 3, 64, 3), (1, 9, 130, 72, 128, 3),
+    (3, 5, 9, 3, 64, 3), (1, 1, 1, 3, 16, 3), (2, 16, 24, 8, 40, 3)])
 def test_conv_bf16_dma(ops, B, H, W, Cin, Cout, k):
     """LDS-DMA bf16 GEMM (gemm16.hip), including the split-K atomics path (deep, few output tiles), channel tails
-    (Cin % 64 != 0, Cin = 3 padded to 8), ragged M and Cout tiles, 1x1 maps whose every tap but the centre is halo."""
+    (Cin % 64 != 0, Cin = 3 padded to 8: the tap-packed K axis), ragged M and Cout tiles, 1x1 maps whose every tap but the centre is halo."""
     def bf(z):
         u = np.ascontiguousarray(z, dtype=np.float32).view(np.uint32)
         return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
