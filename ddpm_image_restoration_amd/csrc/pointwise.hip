@@ -463,43 +463,50 @@ __global__ void avif_combine_k(const float* __restrict__ base, const float* __re
 }
 
 // ------------------------------------------------------------------------------------------- time embedding
-// one workgroup per sample: sinusoid -> Linear(256,1024) -> SiLU -> Linear(1024,256)
-__global__ __launch_bounds__(256) void time_embed_k(const float* __restrict__ t, TimeEmbedW w,
-                                                    float* __restrict__ hidden, float* __restrict__ temb) {
-  __shared__ float e[256];
-  __shared__ float h[1024];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  {
-    const int k = tid & 127;
-    const float coef = (float)(-9.210340371976184 / 127.0);   // -ln(10000)/(half-1), rounded to fp32 like torch
-    const float f = expf((float)k * coef);
-    const float a = t[b] * f;
-    e[tid] = tid < 128 ? sinf(a) : cosf(a);
-  }
-  __syncthreads();
-  for (int n = tid; n < 1024; n += 256) {
-    const float* wr = w.w0 + (size_t)n * 256;
-    float acc = 0.f;
-    for (int k = 0; k < 256; k += 4) {
-      float4 wv = *reinterpret_cast<const float4*>(wr + k);
-      acc = fmaf(wv.x, e[k], acc); acc = fmaf(wv.y, e[k + 1], acc);
-      acc = fmaf(wv.z, e[k + 2], acc); acc = fmaf(wv.w, e[k + 3], acc);
+// sinusoid -> Linear(256,1024) -> SiLU -> Linear(1024,256) (webp_inference.py:145-151), two launches: one wave per output
+// unit streams its weight row once (coalesced float4 per lane) and forms the dot product for every sample of the batch
+// (the one-workgroup-per-sample version walked 1 KiB-strided rows per thread: 72 us per forward).
+__global__ __launch_bounds__(256) void time_embed1_k(const float* __restrict__ t, TimeEmbedW w, int B, float* __restrict__ hidden) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x * 4 + wave;                      // hidden unit 0..1023
+  const float4 wv = *reinterpret_cast<const float4*>(w.w0 + (size_t)n * 256 + 4 * lane);
+  const float coef = (float)(-9.210340371976184 / 127.0);   // -ln(10000)/(half-1), rounded to fp32 like torch
+  float f[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) f[j] = expf((float)((4 * lane + j) & 127) * coef);
+  const float bias = w.b0[n];
+  for (int b = 0; b < B; ++b) {
+    const float tb = t[b];
+    float e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float a = tb * f[j]; e[j] = (4 * lane + j) < 128 ? sinf(a) : cosf(a); }
+    float acc = fmaf(wv.x, e[0], fmaf(wv.y, e[1], fmaf(wv.z, e[2], wv.w * e[3])));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) {
+      acc += bias;
+      hidden[(size_t)b * 1024 + n] = acc / (1.0f + __expf(-acc));
     }
-    acc += w.b0[n];
-    float s = acc / (1.0f + __expf(-acc));
-    h[n] = s;
-    hidden[(size_t)b * 1024 + n] = s;
   }
-  __syncthreads();
-  {
-    const float* wr = w.w2 + (size_t)tid * 1024;
+}
+
+__global__ __launch_bounds__(256) void time_embed2_k(const float* __restrict__ hidden, TimeEmbedW w, int B, float* __restrict__ temb) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x * 4 + wave;                      // output 0..255
+  float4 wv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const float4*>(w.w2 + (size_t)n * 1024 + q * 256 + 4 * lane);
+  const float bias = w.b2[n];
+  for (int b = 0; b < B; ++b) {
     float acc = 0.f;
-    for (int k = 0; k < 1024; k += 4) {
-      float4 wv = *reinterpret_cast<const float4*>(wr + k);
-      acc = fmaf(wv.x, h[k], acc); acc = fmaf(wv.y, h[k + 1], acc);
-      acc = fmaf(wv.z, h[k + 2], acc); acc = fmaf(wv.w, h[k + 3], acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 h = *reinterpret_cast<const float4*>(hidden + (size_t)b * 1024 + q * 256 + 4 * lane);
+      acc = fmaf(wv[q].x, h.x, acc); acc = fmaf(wv[q].y, h.y, acc); acc = fmaf(wv[q].z, h.z, acc); acc = fmaf(wv[q].w, h.w, acc);
     }
-    temb[(size_t)b * 256 + tid] = acc + w.b2[tid];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) temb[(size_t)b * 256 + n] = acc + bias;
   }
 }
 
@@ -682,7 +689,8 @@ void launch_mul4_add(const float* base, int ldb, const float* a, int lda, const 
 
 void launch_time_embed(const float* t, int B, const TimeEmbedW& w, float* hidden, float* temb, float* tproj,
                        hipStream_t s) {
-  hipLaunchKernelGGL(time_embed_k, dim3(B), dim3(256), 0, s, t, w, hidden, temb);
+  hipLaunchKernelGGL(time_embed1_k, dim3(256), dim3(256), 0, s, t, w, B, hidden);
+  hipLaunchKernelGGL(time_embed2_k, dim3(64), dim3(256), 0, s, hidden, w, B, temb);
   hipLaunchKernelGGL(time_proj_k, dim3(cdiv(w.NT, 256), B), dim3(256), 0, s, temb, w, tproj);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
