@@ -461,8 +461,8 @@ hipEvent_t Context::prof_event() {
 }
 void Context::prof_begin(int cls, double flops, hipStream_t s) {
   prof_open_ = false;
-  // an event record costs a ~4 us marker dispatch on the stream: the coarse level (1) brackets the forward and its two
-  // full-resolution attention launches only -- 6 records per forward instead of 54 (0.2 ms of a 64 ms timestep)
+  // the coarse level (1) brackets the forward and its two full-resolution attention launches only -- 6 event records per
+  // forward instead of 54 -- so that the measured stream carries as few markers as the roofline figures need
   if (!prof_on_ || (cls == PROF_ATTN && prof_detail_ < 2)) return;
   ProfSpan sp{prof_event(), prof_event(), cls, flops};
   DDPMIR_HIP_CHECK(hipEventRecord(sp.a, s));

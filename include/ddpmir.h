@@ -136,7 +136,7 @@ int ddpmir_jpeg_roundtrip_u8(ddpmir_ctx* ctx, const uint8_t* in_u8_nchw, uint8_t
  * tokens of the full-resolution blocks), "attention" (all 13; needs enable = 2), "forward" (whole U-Net forwards),
  * "codec_host" (HOST milliseconds spent inside the codec callback / built-in pool of the sampling loop, and the number of
  * calls).  enable = 1 brackets the forwards and the full-resolution attention launches only (6 event records per
- * forward); enable = 2 every attention launch (54 records, ~0.2 ms of stream time per forward); 0 stops. */
+ * forward); enable = 2 every attention launch (54 records per forward); 0 stops. */
 int ddpmir_profile_enable(ddpmir_ctx* ctx, int enable);
 int ddpmir_profile_read(ddpmir_ctx* ctx, const char* cls, double* ms, int64_t* launches, double* flops);
 const char* ddpmir_version(void);
