@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
   }
 }
 
-// out[m][n] = sum_s ws[s][m][n] (s ascending) + bias + time bias + residual, optional bf16 copy
+// out[m][n] = epilogue(sum_s ws[s][m][n]) (s ascending): bias, time bias, activation, factors, residual; optional bf16 / e4m3 copy
 __global__ void splitk_reduce_k(const IGemm p, int nsplit, int64_t M, int HW) {
   const int C4 = p.Cout / 4;
   const int64_t total = M * C4;
@@ -465,6 +465,10 @@ __global__ void splitk_reduce_k(const IGemm p, int nsplit, int64_t M, int HW) {
       const float4 t = *reinterpret_cast<const float4*>(p.tb + (size_t)(m / HW) * p.ldtb + n);
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
+    // (the rest of the main kernel's epilogue, in its order: activation, elementwise factor, per-sample factor)
+    if (p.epi_act != ACT_NONE) { v.x = act_apply(v.x, p.epi_act); v.y = act_apply(v.y, p.epi_act); v.z = act_apply(v.z, p.epi_act); v.w = act_apply(v.w, p.epi_act); }
+    if (p.mul) { const float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + n); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+    if (p.rowscale) { const float rs = p.rowscale[m / HW]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
     if (p.res) { const float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
     if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + n) = v;
     if (out16) {
@@ -541,8 +545,8 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   const bool tap_pack = !F8 && p.taps == 9 && p.Cin == 8 && p.lda16 == 8 && !p.Cinb;
   const int nit = tap_pack ? cdiv(9, BK / 8) : p.taps * cdiv(p.Cin, F8 ? 2 * BK : BK) + cdiv(p.Cinb, BK);
   int nsplit = 1;
-  const bool linear = p.epi_act == ACT_NONE && !p.mul && !p.rowscale && p.epi_mask == MASK_NONE && (p.out || p.out16 || p.out8) && !p.pk_q &&
-                      !p.sel_C && !p.gn_sums && p.splitk_ws;
+  // split-K needs an epilogue that splitk_reduce_k can replay on the summed tile: bias, time bias, activation, factors, residual
+  const bool linear = p.epi_mask == MASK_NONE && (p.out || p.out16 || p.out8) && !p.pk_q && !p.sel_C && !p.gn_sums && p.splitk_ws;
   if (linear && gx * gy < 256 && nit >= 8 * (64 / BK)) {
     nsplit = std::min(std::min(16, nit / (4 * (64 / BK))), cdiv(512, gx * gy));
     nsplit = std::min<int64_t>(nsplit, (int64_t)(p.splitk_ws_bytes / ((size_t)M * p.Cout * sizeof(float))));
