@@ -547,7 +547,7 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   int nsplit = 1;
   // split-K needs an epilogue that splitk_reduce_k can replay on the summed tile: bias, time bias, activation, factors, residual
   const bool linear = p.epi_mask == MASK_NONE && (p.out || p.out16 || p.out8) && !p.pk_q && !p.sel_C && !p.gn_sums && p.splitk_ws;
-  if (linear && gx * gy < 256 && nit >= 8 * (64 / BK)) {
+  if (linear && gx * gy <= 256 && nit >= 8 * (64 / BK)) {
     nsplit = std::min(std::min(16, nit / (4 * (64 / BK))), cdiv(512, gx * gy));
     nsplit = std::min<int64_t>(nsplit, (int64_t)(p.splitk_ws_bytes / ((size_t)M * p.Cout * sizeof(float))));
     if (nsplit < 1) nsplit = 1;
