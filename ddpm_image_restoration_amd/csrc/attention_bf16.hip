@@ -507,13 +507,20 @@ __global__ __launch_bounds__(256) void attn_pair_bounds_k(const __bf16* __restri
   }
 }
 
-template <int D, int QS, int TS>
+template <int D, int QS, int TS, int SDEN = 0>
 __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
                                                         const PairBounds* __restrict__ bounds, float* __restrict__ out, int ldo,
                                                         int N, int NT, int heads, int nqb, int npairs, __bf16* __restrict__ out16) {
   using G = AttnGeom<D>;
   using SG = StageGeom<D, TS>;
-  static_assert(G::ONES && G::DT == 1 && G::KC == 1, "no-max variant: head_dim <= 16 (denominator from the ones row)");
+  // head_dim <= 16: the denominator comes out of the ones row of V^T.  head_dim 32 has no spare accumulator row: either an
+  // all-ones A operand feeds a second accumulator tile whose every row is the column sum of P (SDEN = 0: two more MFMAs per
+  // 32 keys, six in all -- matrix pipe 192 cycles per 1024 scores beside 212 of VALU issue) or the lane adds its sixteen p's
+  // (SDEN = 1: 64 more VALU cycles, 260 in all, matrix pipe 128).  Measured at B = 16, N = 16 384, 4 heads (tools/attn_ab32.py,
+  // profiles/r02_attn_nomax_headdim32_ab.txt): general kernel 2.77 ms, ones-MFMA 2.78, scalar adds 2.61 (QS = 2, 16 KiB
+  // stages) -- 318 cycles per 1024 scores against the 199 of head_dim 16: with both pipes this full they overlap poorly.
+  // N % 32 == 0 there (host check): without a ones row nothing masks the padding keys of a ragged last tile out of the sum.
+  static_assert(G::DT == 1 && G::KC <= 2, "no-max variant: head_dim <= 32");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 stage buffers
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -529,26 +536,35 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
   if (!pair_is_bounded(bounds, bh)) return;                // this pair goes through the general kernel
   const int b = bh / heads, head = bh - b * heads;
   const int q0 = qb * (128 * QS) + wave * (32 * QS);
-  bf16x8 qf[QS];
+  bf16x8 qf[QS][G::KC];
 #pragma unroll
   for (int u = 0; u < QS; ++u) {
     int qr = q0 + 32 * u + lr;
     if (qr >= NT * 32) qr = NT * 32 - 1;
-    qf[u] = *reinterpret_cast<const bf16x8*>(Qp + ((size_t)bh * NT * 32 + qr) * G::DP + 8 * lh);
+#pragma unroll
+    for (int c = 0; c < G::KC; ++c)
+      qf[u][c] = *reinterpret_cast<const bf16x8*>(Qp + ((size_t)bh * NT * 32 + qr) * G::DP + 16 * c + 8 * lh);
   }
-  f32x16 o[QS];
+  constexpr bool LMFMA = !G::ONES && !SDEN;              // denominator: ones-operand MFMA tile, or (SDEN) scalar adds
+  f32x16 o[QS], lsum[LMFMA ? QS : 1];
+  float lacc[QS][2];
 #pragma unroll
-  for (int u = 0; u < QS; ++u)
+  for (int u = 0; u < QS; ++u) {
+    lacc[u][0] = lacc[u][1] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { o[u][r] = 0.f; if (LMFMA) lsum[u][r] = 0.f; }
+  }
   f32x16 zero16;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+  bf16x8 ones8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones8[j] = (__bf16)1.0f;
 
   const unsigned char* gkv = KVp + (size_t)bh * NT * G::TILE_BYTES;
   const int nstages = (NT + TS - 1) / TS;
   const size_t total_bytes = (size_t)NT * G::TILE_BYTES;
-  const int vrow = lr < D ? lr : D;                        // row of the V^T slab this lane reads (row D = ones)
+  const int vrow = G::ONES ? (lr < D ? lr : D) : lr;       // row of the V^T slab this lane reads (row D = ones)
   const unsigned lds0 = (unsigned)(size_t)lds;
   auto dma = [&](int stage, int buf) {
     const unsigned char* src = gkv + (size_t)stage * SG::STAGE_BYTES;
@@ -567,23 +583,33 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
     if (st + 1 < nstages) dma(st + 1, buf ^ 1);
     const unsigned char* sb = lds + buf * SG::STAGE_BYTES;
     const int tiles_here = min(TS, NT - st * TS);
-    bf16x8 kA, vA[2], kB, vB[2];
-    auto fetch = [&](int t, bf16x8& k_, bf16x8 (&v_)[2]) {
+    bf16x8 kA[G::KC], vA[2], kB[G::KC], vB[2];
+    auto fetch = [&](int t, bf16x8 (&k_)[G::KC], bf16x8 (&v_)[2]) {
       const unsigned char* tb = sb + t * G::TILE_BYTES;
-      k_ = *reinterpret_cast<const bf16x8*>(tb + lane * 16);
+#pragma unroll
+      for (int c = 0; c < G::KC; ++c) k_[c] = *reinterpret_cast<const bf16x8*>(tb + c * 1024 + lane * 16);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
         v_[s2] = *reinterpret_cast<const bf16x8*>(tb + G::KT_BYTES + (s2 * 2 + lh) * (G::RV * 16) + vrow * 16);
     };
-    auto process = [&](const bf16x8& kf, const bf16x8 (&vf)[2]) {
+    auto process = [&](const bf16x8 (&kf)[G::KC], const bf16x8 (&vf)[2]) {
 #pragma unroll
       for (int u = 0; u < QS; ++u) {
-        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u], zero16, 0, 0, 0);
+        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[u][0], zero16, 0, 0, 0);
+        if constexpr (G::KC == 2) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[u][1], s, 0, 0, 0);
         bf16x8 pb[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(s[r]);
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(s[r]);
+          if constexpr (!G::ONES && SDEN) lacc[u][r & 1] += pv;
+          pb[r >> 3][r & 7] = (__bf16)pv;
+        }
         o[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb[0], o[u], 0, 0, 0);
         o[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb[1], o[u], 0, 0, 0);
+        if constexpr (LMFMA) {
+          lsum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[0], lsum[u], 0, 0, 0);
+          lsum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[1], lsum[u], 0, 0, 0);
+        }
       }
     };
     fetch(0, kA, vA);
@@ -599,7 +625,11 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
   }
 #pragma unroll
   for (int u = 0; u < QS; ++u) {
-    const float l = __shfl(o[u][(D / 8) * 4], lr);        // row D of O^T: register (D/8)*4 of lane half 0
+    // row D of O^T: register (D/8)*4 of lane half 0; or any row of the ones-operand tile (its column sums of P)
+    float l;
+    if constexpr (G::ONES) l = __shfl(o[u][(D / 8) * 4], lr);
+    else if constexpr (LMFMA) l = lsum[LMFMA ? u : 0][0];
+    else { l = lacc[u][0] + lacc[u][1]; l += __shfl_xor(l, 32); }   // the lane halves hold the two key halves of a query
     const float inv = 1.0f / l;
     const int qr = q0 + 32 * u + lr;
     if (qr < N) {
@@ -624,7 +654,7 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
   }
 }
 
-template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT, int WPS = 0, int DMA = 1, int DEN = 0, int NMTS = 0, int NMQS = 2>
+template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT, int WPS = 0, int DMA = 1, int DEN = 0, int NMTS = 0, int NMQS = 2, int NMSD = 0>
 void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* ws, hipStream_t s,
                void* out16) {
   using G = AttnGeom<D>;
@@ -653,11 +683,11 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
     hipLaunchKernelGGL(attn_pair_bounds_k<G::DP>, dim3(NT >= 256 ? 32 : 1, BH), dim3(256), 0, s, (const __bf16*)Qp, (const float*)Kmax, NT, flags);
     static PerDeviceOnce attr_nm;
     attr_nm.run([] {
-      DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16_nm<D, NMQS, NMTS>),
+      DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16_nm<D, NMQS, NMTS, NMSD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SN::STAGE_BYTES));
     });
     const int nqb_nm = (N + 128 * NMQS - 1) / (128 * NMQS);
-    hipLaunchKernelGGL((flash_bf16_nm<D, NMQS, NMTS>), dim3((unsigned)(nqb_nm * BH)), dim3(256), 2 * SN::STAGE_BYTES, s, (const __bf16*)Qp,
+    hipLaunchKernelGGL((flash_bf16_nm<D, NMQS, NMTS, NMSD>), dim3((unsigned)(nqb_nm * BH)), dim3(256), 2 * SN::STAGE_BYTES, s, (const __bf16*)Qp,
                        (const unsigned char*)KVp, (const PairBounds*)flags, out, ldo, N, NT, heads, nqb_nm, BH, reinterpret_cast<__bf16*>(out16));
     skip = flags;
   }
@@ -738,6 +768,13 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
       case 26: run_flash<32, 2, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 27: run_flash<32, 1, 8, 3, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 30: run_flash<32, 2, 4, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 50: run_flash<32, 2, 8, 0, 1, 1, 4, 2, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 51: run_flash<32, 2, 8, 0, 1, 1, 4, 2, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 52: run_flash<32, 2, 8, 0, 1, 1, 4, 4, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 53: run_flash<32, 2, 8, 0, 1, 1, 4, 3, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 54: run_flash<32, 2, 8, 0, 1, 1, 8, 2, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 55: run_flash<32, 2, 8, 0, 1, 1, 2, 4, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 56: run_flash<32, 2, 8, 0, 1, 1, 2, 2, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 31: run_flash<32, 2, 16, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 28: run_flash<32, 1, 4, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
       case 29: run_flash<32, 1, 6, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
@@ -781,7 +818,10 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
     // (A/B on one device, B=4, N=65 536: general kernel 7.30 ms; no-max QS/TS 2/12 6.96, 2/8 6.97, 3/8 7.09, 4/8 6.84)
     case 8: run_flash<8, 2, 16, 0, 1, 0, 8, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     case 16: run_flash<16, 2, 16, 0, 1, 0, 8, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
-    case 32: run_flash<32, 2, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;   // scalar-add denominators: tools/attn_ab32.py
+    case 32:   // bounded scores: no-max kernel at 3 waves/SIMD (16 KiB stages, scalar-add denominators); general kernel otherwise
+      if ((N % 32) == 0) run_flash<32, 2, 8, 0, 1, 1, 4, 2, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16);
+      else run_flash<32, 2, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16);
+      break;
     case 64: run_flash<64, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     case 128: run_flash<128, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     default: throw std::runtime_error("attention_bf16: unsupported head dim");
