@@ -23,4 +23,4 @@ done
 python3 bench.py --full --no-cpu-baseline > gpurun_out/r02_jpeg_full_T1000.json 2>> gpurun_out/r02_c5.err
 python3 bench.py --full --no-cpu-baseline --arch avif --T 250 > gpurun_out/r02_avif_full_T250.json 2>> gpurun_out/r02_c5.err
 python3 bench.py --full --no-cpu-baseline --arch webp > gpurun_out/r02_webp_full_T1000.json 2>> gpurun_out/r02_c5.err
-tail -1 gpurun_out/r02_jpeg_forward_timeline.txt gpurun_out/r02_c5_forward_timeline.txt
+tail -n 1 gpurun_out/r02_jpeg_forward_timeline.txt; tail -n 1 gpurun_out/r02_c5_forward_timeline.txt
