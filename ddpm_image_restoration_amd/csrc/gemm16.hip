@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
       for (int off = 1; off < span; off <<= 1) { gs1 += __shfl_xor(gs1, off); gs2 += __shfl_xor(gs2, off); }
       if (rsub == 0 && (c4 % span) == 0) {
         const int b = (m0 + wave * 32) / HW;
-        double* dst = p.gn_sums + ((size_t)b * p.gn_groups + n / cpg) * 2;
+        double* dst = p.gn_sums + (((size_t)b * GN_SUM_SLOTS + (blockIdx.x & (GN_SUM_SLOTS - 1))) * p.gn_groups + n / cpg) * 2;
         atomicAdd(dst, (double)gs1);
         atomicAdd(dst + 1, (double)gs2);
       }

@@ -149,7 +149,7 @@ class Context {
     unsigned char* zero16 = nullptr;
     float* splitk_ws = nullptr;
     double* gn_partial = nullptr;
-    double* gn_sums = nullptr;   // [B][8][2] statistics accumulated by a GEMM epilogue (conv1 -> norm2)
+    double* gn_sums = nullptr;   // [B][GN_SUM_SLOTS][8][2] statistics accumulated by a GEMM epilogue (conv1 -> norm2)
     float *sc1 = nullptr, *sh1 = nullptr, *sc2 = nullptr, *sh2 = nullptr;
     float *hidden = nullptr, *temb = nullptr, *tproj = nullptr;
     float *boost = nullptr, *boost2 = nullptr, *constmix = nullptr;

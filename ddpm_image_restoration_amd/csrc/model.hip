@@ -368,7 +368,7 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
   }
   int max_splits = gn_splits(H * W, 64);
   p.gn_partial = a.take<double>((size_t)B * 8 * max_splits * 2 + 64);
-  p.gn_sums = a.take<double>((size_t)B * 8 * 2 + 64);
+  p.gn_sums = a.take<double>((size_t)B * GN_SUM_SLOTS * 8 * 2 + 64);
   p.sc1 = a.take<float>((size_t)B * 1024); p.sh1 = a.take<float>((size_t)B * 1024);
   p.sc2 = a.take<float>((size_t)B * 1024); p.sh2 = a.take<float>((size_t)B * 1024);
   p.hidden = a.take<float>((size_t)B * 1024); p.temb = a.take<float>((size_t)B * 256);
@@ -657,7 +657,7 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   // (DDPMIR_FP8: the deep 3x3 convs take their operand as e4m3 instead -- written by the same pass)
   const bool c1_f8 = bw.conv1.w8 != nullptr, c2_f8 = bw.conv2.w8 != nullptr, co_f8 = bw.conv_out.w8 != nullptr;
   launch_gn_apply16(in, ldin, B, HW, bw.cinp, p.sc1, p.sh1, ACT_NONE, c1_f8 ? nullptr : p.a16, cin8, bw.has_shortcut ? p.x16 : nullptr,
-                    cin8, s, fuse_gn ? p.gn_sums : nullptr, fuse_gn ? B * gn_groups(C) * 2 : 0, c1_f8 ? p.a8 : nullptr, bw.conv1.cin16);
+                    cin8, s, fuse_gn ? p.gn_sums : nullptr, fuse_gn ? B * GN_SUM_SLOTS * gn_groups(C) * 2 : 0, c1_f8 ? p.a8 : nullptr, bw.conv1.cin16);
   if (fuse_gn) { c1.gn_sums = p.gn_sums; c1.gn_groups = gn_groups(C); }
   if (c1_f8) { c1.A16 = p.a8; c1.lda16 = bw.conv1.cin16; conv8(bw.conv1, c1, s); }
   else conv16(bw.conv1, c1, s);

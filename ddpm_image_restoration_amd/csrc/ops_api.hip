@@ -255,11 +255,18 @@ int ddpmir_op_conv_gnstats_bf16(const float* x, int B, int H, int W, int Cin, co
     float* o = d.alloc<float>(M * Cout);
     p.out = o; p.ldo = Cout;
     if (!gemm16_can_fuse_gn(p, groups)) throw std::runtime_error("conv_gnstats: shape cannot fuse the statistics");
-    double* ds = d.alloc<double>((size_t)B * groups * 2);
+    double* ds = d.alloc<double>((size_t)B * GN_SUM_SLOTS * groups * 2);
     p.gn_sums = ds; p.gn_groups = groups;
     launch_gemm16(p, nullptr);
     d.down(out, o, M * Cout);
-    d.down(sums, ds, (size_t)B * groups * 2);
+    std::vector<double> slots((size_t)B * GN_SUM_SLOTS * groups * 2);
+    d.down(slots.data(), ds, slots.size());
+    for (int b = 0; b < B; ++b)            // fold the accumulator slots of every (sample, group)
+      for (int g = 0; g < groups * 2; ++g) {
+        double t = 0.0;
+        for (int sl = 0; sl < GN_SUM_SLOTS; ++sl) t += slots[((size_t)b * GN_SUM_SLOTS + sl) * groups * 2 + g];
+        sums[(size_t)b * groups * 2 + g] = t;
+      }
   });
 }
 

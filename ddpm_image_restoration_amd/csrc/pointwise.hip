@@ -592,7 +592,7 @@ void launch_gn_scale_shift(const float* x, int ldx, int B, int HW, int C, int G,
 
 void launch_gn_from_sums(const double* sums, int B, int HW, int C, int G, const float* gamma, const float* beta, float* scale,
                          float* shift, hipStream_t stream) {
-  hipLaunchKernelGGL(gn_finalize, dim3(G, B), dim3(64), 0, stream, sums, 1, HW, C, round_up(C, 4), G, gamma, beta, scale, shift);
+  hipLaunchKernelGGL(gn_finalize, dim3(G, B), dim3(64), 0, stream, sums, GN_SUM_SLOTS, HW, C, round_up(C, 4), G, gamma, beta, scale, shift);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
