@@ -157,6 +157,7 @@ class Context {
     float *s_xt = nullptr, *s_theta = nullptr, *s_y = nullptr, *s_noise = nullptr, *s_t = nullptr;
     StepParams* sp = nullptr;          // [2] per-lane step scalars on the device
     GraphSlot g_front[2], g_back[2][2];   // captured timestep halves per lane (back: without / with the phase fix)
+    GraphSlot g_head[2], g_mid, g_tail[2];  // two-lane loops: down1 per lane, the levels below for both, up5 + head + D2H per lane
     LoopConsts lg_key; int lg_nl = 0;
     uint8_t *s_u8 = nullptr, *s_dec = nullptr, *s_jpeg = nullptr;
     float* dft[10] = {nullptr};
@@ -171,6 +172,11 @@ class Context {
   void free_plan();
 
   void forward(const float* x, const float* t, const float* cl, float* out, hipStream_t s);
+  // forward() in three pieces (model.hip): the full-resolution blocks per row range, the levels below for the whole batch
+  void fwd_head(const float* x, const float* t, const float* cl, int row0, int nb, bool whole, hipStream_t s);
+  void fwd_mid(int B, bool whole, hipStream_t s);
+  void fwd_tail(float* out, int row0, int nb, bool whole, hipStream_t s);
+  void prof_close_forward(hipStream_t s);
   void run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
   void run_block16(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
   void conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override = nullptr);
@@ -192,7 +198,7 @@ class Context {
   hipEvent_t lane_ev_[2] = {nullptr, nullptr};
 
   // ---- HIP-event profiling of kernel classes
-  struct ProfSpan { hipEvent_t a, b; int cls; double flops; };
+  struct ProfSpan { hipEvent_t a, b; int cls; double flops; int count = 1; };
   std::vector<ProfSpan> prof_spans_;
   std::vector<hipEvent_t> prof_pool_;
   bool prof_on_ = false, prof_open_ = false;

@@ -479,7 +479,7 @@ void Context::prof_collect() {
     DDPMIR_HIP_CHECK(hipEventSynchronize(sp.b));
     float ms = 0.f;
     DDPMIR_HIP_CHECK(hipEventElapsedTime(&ms, sp.a, sp.b));
-    prof_ms_[sp.cls] += ms; prof_n_[sp.cls] += 1; prof_flops_[sp.cls] += sp.flops;
+    prof_ms_[sp.cls] += ms; prof_n_[sp.cls] += sp.count; prof_flops_[sp.cls] += sp.flops;
     if (sp.cls == PROF_ATTN_L0) { prof_ms_[PROF_ATTN] += ms; prof_n_[PROF_ATTN] += 1; prof_flops_[PROF_ATTN] += sp.flops; }
     prof_pool_.push_back(sp.a); prof_pool_.push_back(sp.b);
   }
@@ -811,18 +811,60 @@ void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int 
   conv(bw.conv_out, co, s);
 }
 
-void Context::forward(const float* x, const float* t, const float* cl, float* out, hipStream_t s) {
-  Plan& p = plan_;
-  const int B = fb_, H = p.H, W = p.W;
-  prof_begin(PROF_FWD, 0.0, s);
-  launch_nchw3_to_nhwc4(x, p.x4, B, H, W, s);
-  launch_time_embed(t, B, tw_, p.hidden, p.temb, p.tproj, s);
-  if (cfg.arch == DDPMIR_ARCH_AVIF) {
-    launch_cl_boost(cl, B, 0.5f, 0.5f, 0.3f, 1.5f, p.boost, s);    // colour   avif_inference.py:246
-    launch_cl_boost(cl, B, 0.7f, 0.3f, 0.5f, 1.3f, p.boost2, s);   // edge     avif_inference.py:247
-  } else {
-    launch_cl_boost(cl, B, 0.f, 1.f, k.boost_lo, k.boost_hi, p.boost, s);   // webp_inference.py:263
+// The U-Net forward in three pieces so that the two-lane sampling loop can run the full-resolution blocks per lane (their
+// inputs / outputs are what the host codec produces / consumes) and everything below level 0 ONCE for both lanes:
+//   fwd_head(rows)  image -> NHWC, time embedding, down1                      for samples [row0, row0 + nb)
+//   fwd_mid(B)      max-pool, down2 .. bottleneck .. up4                      for all B samples
+//   fwd_tail(rows)  up5, head conv, tanh -> NCHW                              for samples [row0, row0 + nb)
+// forward() = the three pieces on the whole batch (same launch sequence as one function).
+namespace {
+// per-sample side inputs (time projections, cl boosts) of a row range: the block code indexes them from sample 0
+struct SideRows {
+  float *&tproj, *&boost, *&boost2, *&constmix;
+  float *t0, *b0, *b20, *c0;
+  SideRows(float*& tp, float*& bo, float*& bo2, float*& cm, int row0, int nt)
+      : tproj(tp), boost(bo), boost2(bo2), constmix(cm), t0(tp), b0(bo), b20(bo2), c0(cm) {
+    tproj += (size_t)row0 * nt; boost += row0; boost2 += row0; constmix += row0;
   }
+  ~SideRows() { tproj = t0; boost = b0; boost2 = b20; constmix = c0; }
+};
+}  // namespace
+
+void Context::prof_close_forward(hipStream_t s) {
+  if (!prof_on_) return;   // close the "forward" span (the attention spans nested inside are already closed)
+  for (auto it = prof_spans_.rbegin(); it != prof_spans_.rend(); ++it)
+    if (it->cls == PROF_FWD) { DDPMIR_HIP_CHECK(hipEventRecord(it->b, s)); break; }
+}
+
+void Context::fwd_head(const float* x, const float* t, const float* cl, int row0, int nb, bool whole, hipStream_t s) {
+  Plan& p = plan_;
+  const int H = p.H, W = p.W;
+  const size_t HW = (size_t)H * W;
+  fb_ = nb;
+  prof_begin(PROF_FWD, 0.0, s);
+  if (!whole && prof_on_ && !prof_spans_.empty()) prof_spans_.back().count = 0;   // a piece: its time counts, not its number
+  float* x4 = p.x4 + (size_t)row0 * HW * 4;
+  launch_nchw3_to_nhwc4(x, x4, nb, H, W, s);
+  launch_time_embed(t, nb, tw_, p.hidden + (size_t)row0 * 1024, p.temb + (size_t)row0 * 256, p.tproj + (size_t)row0 * nt_total_, s);
+  if (cfg.arch == DDPMIR_ARCH_AVIF) {
+    launch_cl_boost(cl, nb, 0.5f, 0.5f, 0.3f, 1.5f, p.boost + row0, s);    // colour   avif_inference.py:246
+    launch_cl_boost(cl, nb, 0.7f, 0.3f, 0.5f, 1.3f, p.boost2 + row0, s);   // edge     avif_inference.py:247
+  } else {
+    launch_cl_boost(cl, nb, 0.f, 1.f, k.boost_lo, k.boost_hi, p.boost + row0, s);   // webp_inference.py:263
+  }
+  {
+    SideRows rows(p.tproj, p.boost, p.boost2, p.constmix, row0, nt_total_);
+    // the skip tensor goes straight into the second half of up5's concat buffer
+    run_block(blocks_[0], x4, 4, H, W, p.cat[0] + (size_t)row0 * HW * 128 + 64, 128, s);
+  }
+  if (!whole) prof_close_forward(s);
+}
+
+void Context::fwd_mid(int B, bool whole, hipStream_t s) {
+  Plan& p = plan_;
+  const int H = p.H, W = p.W;
+  fb_ = B;
+  if (!whole) { prof_begin(PROF_FWD, 0.0, s); if (prof_on_ && !prof_spans_.empty()) prof_spans_.back().count = 0; }
   auto hh = [&](int l) { return H >> l; };
   auto ww = [&](int l) { return W >> l; };
   // skip tensors are written straight into the second half of the matching up block's concat buffer
@@ -830,8 +872,9 @@ void Context::forward(const float* x, const float* t, const float* cl, float* ou
   const int skip_off[5] = {64, 128, 256, 512, 512};
   const int skip_c[5] = {64, 128, 256, 512, 512};
   // down path
-  const float* in = p.x4; int ldin = 4;
-  for (int l = 0; l < 5; ++l) {
+  launch_maxpool2(p.cat[0] + skip_off[0], cat_c[0], p.pin[1], skip_c[0], B, hh(0), ww(0), skip_c[0], s);
+  const float* in = p.pin[1]; int ldin = skip_c[0];
+  for (int l = 1; l < 5; ++l) {
     float* d = p.cat[l] + skip_off[l];
     run_block(blocks_[l], in, ldin, hh(l), ww(l), d, cat_c[l], s);
     launch_maxpool2(d, cat_c[l], p.pin[l + 1], skip_c[l], B, hh(l), ww(l), skip_c[l], s);
@@ -842,32 +885,54 @@ void Context::forward(const float* x, const float* t, const float* cl, float* ou
   run_block(blocks_[7], p.bb1, 1024, hh(5), ww(5), p.bb2, 512, s);
   // up path: cat[upsampled, skip]                           webp_inference.py:389-393
   const float* prev = p.bb2; int prev_c = 512;
-  for (int l = 4; l >= 0; --l) {
+  for (int l = 4; l >= 1; --l) {
     launch_upsample2(prev, prev_c, p.cat[l], cat_c[l], B, hh(l + 1), ww(l + 1), prev_c, s);
     const BlockW& bw = blocks_[8 + (4 - l)];
     run_block(bw, p.cat[l], cat_c[l], hh(l), ww(l), p.u[l], bw.cout, s);
     prev = p.u[l]; prev_c = bw.cout;
   }
+  if (!whole) prof_close_forward(s);
+}
+
+void Context::fwd_tail(float* out, int row0, int nb, bool whole, hipStream_t s) {
+  Plan& p = plan_;
+  const int H = p.H, W = p.W;
+  const size_t HW = (size_t)H * W;
+  fb_ = nb;
+  if (!whole) prof_begin(PROF_FWD, 0.0, s);            // (counts as the lane's forward)
+  SideRows rows(p.tproj, p.boost, p.boost2, p.constmix, row0, nt_total_);
+  const BlockW& bw = blocks_[12];
+  const int prev_c = blocks_[11].cout;
+  float* cat0 = p.cat[0] + (size_t)row0 * HW * 128;
+  float* u0 = p.u[0] + (size_t)row0 * HW * bw.cout;
+  launch_upsample2(p.u[1] + (size_t)row0 * (HW / 4) * prev_c, prev_c, cat0, 128, nb, H >> 1, W >> 1, prev_c, s);
+  run_block(bw, cat0, 128, H, W, u0, bw.cout, s);
   // head: u5 + mix * transform(u5) -> GroupNorm(8) -> SiLU -> conv 64->3 -> tanh     webp_inference.py:396-399
   if (cfg.arch == DDPMIR_ARCH_AVIF)
-    avif_transform(head_at_, p.u[0], 64, 64, H, W, p.xd, p.hid, p.S, 64, p.constmix, p.u[0], 64, s);
+    avif_transform(head_at_, u0, 64, 64, H, W, p.xd, p.hid, p.S, 64, p.constmix, u0, 64, s);
   else
-    launch_block_transform(p.u[0], 64, p.S, 64, B, H, W, 64, k.dct_block, head_dct_, 0, 1.0f, k.head_mix, s);
-  launch_gn_scale_shift(p.S, 64, B, H * W, 64, 8, head_g_, head_b_, p.gn_partial, p.sc1, p.sh1, s);
+    launch_block_transform(u0, 64, p.S, 64, nb, H, W, 64, k.dct_block, head_dct_, 0, 1.0f, k.head_mix, s);
+  launch_gn_scale_shift(p.S, 64, nb, H * W, 64, 8, head_g_, head_b_, p.gn_partial, p.sc1, p.sh1, s);
   if (use_gemm16()) {   // SiLU(GN(.)) as a bf16 operand -> DMA GEMM with Cout padded to 4 -> tanh + NCHW in one pass
-    launch_gn_apply16(p.S, 64, B, H * W, 64, p.sc1, p.sh1, ACT_SILU, p.a16, 64, nullptr, 0, s);
-    IGemm hc; hc.B = B; hc.H = H; hc.W = W; hc.A16 = p.a16; hc.lda16 = 64; hc.out = p.x4; hc.ldo = 4;   // x4 is free again
+    float* x4 = p.x4 + (size_t)row0 * HW * 4;          // the lane's image rows are free again
+    launch_gn_apply16(p.S, 64, nb, H * W, 64, p.sc1, p.sh1, ACT_SILU, p.a16, 64, nullptr, 0, s);
+    IGemm hc; hc.B = nb; hc.H = H; hc.W = W; hc.A16 = p.a16; hc.lda16 = 64; hc.out = x4; hc.ldo = 4;
     conv16(head_conv_, hc, s);
-    launch_nhwc4_to_nchw3_tanh(p.x4, out, B, H, W, s);
+    launch_nhwc4_to_nchw3_tanh(x4, out, nb, H, W, s);
   } else {
-    IGemm hc; hc.B = B; hc.H = H; hc.W = W; hc.A = p.S; hc.lda = 64; hc.scale = p.sc1; hc.shift = p.sh1;
+    IGemm hc; hc.B = nb; hc.H = H; hc.W = W; hc.A = p.S; hc.lda = 64; hc.scale = p.sc1; hc.shift = p.sh1;
     hc.pro_act = ACT_SILU; hc.epi_act = ACT_TANH; hc.out = out; hc.ldo = 0; hc.store = STORE_NCHW;
     conv(head_conv_, hc, s);
   }
-  if (prof_on_) {  // close the "forward" span (the attention spans nested inside are already closed)
-    for (auto it = prof_spans_.rbegin(); it != prof_spans_.rend(); ++it)
-      if (it->cls == PROF_FWD) { DDPMIR_HIP_CHECK(hipEventRecord(it->b, s)); break; }
-  }
+  prof_close_forward(s);
+}
+
+void Context::forward(const float* x, const float* t, const float* cl, float* out, hipStream_t s) {
+  const int B = fb_;
+  fwd_head(x, t, cl, 0, B, true, s);
+  fwd_mid(B, true, s);
+  fwd_tail(out, 0, B, true, s);
+  fb_ = B;
 }
 
 void Context::predict(const float* x, const float* t, const float* cl, float* out, int B, int H, int W, hipStream_t s) {
@@ -1068,13 +1133,44 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
     }
   };
 
+  // Two lanes: only the full-resolution blocks run per lane (down1 right after the lane's update, up5 + head right before its
+  // codec); the levels below run once for both lanes, so their latency-bound ~2.5 ms is paid once per timestep.  Stream order
+  // per timestep: head(0) head(1) mid tail(0) tail(1) | codec(0) on the host under tail(1), codec(1) under the next head(0).
+  auto head = [&](int l) {
+    run_or_replay(p.g_head[l], graphs, s, [&] {
+      launch_fill_t_p(p.s_t + l * nb, nb, p.sp + l, s);
+      fwd_head(p.s_xt + l * nh, p.s_t + l * nb, p.s_t + l * nb, l * nb, nb, false, s);
+    });
+  };
+  auto mid = [&] { run_or_replay(p.g_mid, graphs, s, [&] { fwd_mid(B, false, s); }); };
+  auto tail = [&](int l) {
+    run_or_replay(p.g_tail[l], graphs, s, [&] {
+      fwd_tail(p.s_theta + l * nh, l * nb, nb, false, s);
+      launch_quantize_u8(p.s_theta + l * nh, p.s_u8 + l * nh, (int64_t)nh, s);
+      DDPMIR_HIP_CHECK(hipMemcpyAsync(pin_in_ + l * nh, p.s_u8 + l * nh, nh, hipMemcpyDeviceToHost, s));
+    });
+    DDPMIR_HIP_CHECK(hipEventRecord(lane_ev_[l], s));
+  };
+  const bool merged = nl == 2 && !exp_switch("DDPMIR_SEPARATE_LANES");
+
   try {
-    for (int l = 0; l < nl; ++l) front(l);
-    for (int i = i_first; i >= i_last; --i)
-      for (int l = 0; l < nl; ++l) {
-        codec_and_update(l, i);
-        if (i - 1 >= i_last) front(l);
+    if (merged) {
+      head(0); head(1); mid(); tail(0); tail(1);
+      for (int i = i_first; i >= i_last; --i) {
+        const bool more = i - 1 >= i_last;
+        codec_and_update(0, i);
+        if (more) head(0);
+        codec_and_update(1, i);
+        if (more) { head(1); mid(); tail(0); tail(1); }
       }
+    } else {
+      for (int l = 0; l < nl; ++l) front(l);
+      for (int i = i_first; i >= i_last; --i)
+        for (int l = 0; l < nl; ++l) {
+          codec_and_update(l, i);
+          if (i - 1 >= i_last) front(l);
+        }
+    }
   } catch (...) {
     fb_ = B;
     (void)hipStreamSynchronize(s);
@@ -1092,7 +1188,8 @@ void Context::drop_loop_graphs() {
     if (g.graph) (void)hipGraphDestroy(g.graph);
     g = GraphSlot();
   };
-  for (int l = 0; l < 2; ++l) { drop(p.g_front[l]); drop(p.g_back[l][0]); drop(p.g_back[l][1]); }
+  for (int l = 0; l < 2; ++l) { drop(p.g_front[l]); drop(p.g_back[l][0]); drop(p.g_back[l][1]); drop(p.g_head[l]); drop(p.g_tail[l]); }
+  drop(p.g_mid);
 }
 
 }  // namespace ddpmir
