@@ -715,7 +715,8 @@ static_assert(AttnGeom<16>::TILE_BYTES == ATTN16_TILE_BYTES && AttnGeom<16>::KT_
               AttnGeom<16>::RV == ATTN16_RV && AttnGeom<16>::DP == 16, "AttnPack16 geometry out of sync");
 
 bool attention_bf16_prepack_supported(int N, int C, int heads) {
-  return heads == 4 && (C == 64 || C == 128) && (N % 32) == 0 && N >= 64;
+  const int D = heads > 0 ? C / heads : 0;
+  return heads > 0 && heads * D == C && (D == 8 || D == 16 || D == 32) && (C % 64) == 0 && (N % 32) == 0 && N >= 64;
 }
 
 template <int D>
@@ -731,14 +732,21 @@ static AttnPack16 pack_targets_for(int B, int N, int heads, void* ws) {   // sam
   t.ntiles = (int)NT;
   t.qscale = 1.44269504088896340736f / sqrtf((float)D);
   t.D = D;
+  t.heads = heads;
   return t;
 }
 
 static_assert(AttnGeom<32>::TILE_BYTES == 4096 && AttnGeom<32>::KT_BYTES == 2048 && AttnGeom<32>::RV == 32 && AttnGeom<32>::DP == 32,
               "head_dim-32 pack geometry out of sync with gemm16.hip");
+static_assert(AttnGeom<8>::TILE_BYTES == 1024 + 4 * 9 * 16 && AttnGeom<8>::KT_BYTES == 1024 && AttnGeom<8>::RV == 9 && AttnGeom<8>::DP == 16,
+              "head_dim-8 pack geometry out of sync with gemm16.hip");
 
 AttnPack16 attention_bf16_pack_targets(int B, int N, int C, int heads, void* ws) {
-  return C / heads == 32 ? pack_targets_for<32>(B, N, heads, ws) : pack_targets_for<16>(B, N, heads, ws);
+  switch (C / heads) {
+    case 8: return pack_targets_for<8>(B, N, heads, ws);
+    case 32: return pack_targets_for<32>(B, N, heads, ws);
+    default: return pack_targets_for<16>(B, N, heads, ws);
+  }
 }
 
 size_t attention_bf16_workspace(int B, int N, int C, int heads) {

@@ -302,13 +302,14 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
   for (int h = 0; h < NT / HN; ++h) {
     if constexpr (NT == 4) {
       if (p.pk_q) {   // fused qkv projection: this 32-token x 64-column tile is Q, K or V of one 32-key attention tile
-        // 4 heads of head_dim D = 16 or 32 (C = 4 D); a 64-column pass holds 64/D heads = NCH 16-deep chunks each
-        const int D = p.pk_D, C = 4 * D, NCH = D >> 4, HPP = 64 / D;
+        // `heads` heads of head_dim D = 8, 16 or 32 (C = heads * D, a multiple of 64); a 64-column pass holds 64/D heads of
+        // NCH 16-deep chunks each (head_dim 8 is zero-padded to one 16-deep chunk: AttnGeom<8>::DP = 16)
+        const int D = p.pk_D, nheads = p.pk_heads, C = nheads * D, NCH = D < 16 ? 1 : D >> 4, HPP = 64 / D, DPq = D < 16 ? 16 : D;
         const int mrow0 = m0 + wave * 32, nb = n0 + h * BNH;
         if (mrow0 >= M || nb >= 3 * C) continue;
         const int b = mrow0 / HW, tile = (mrow0 - b * HW) >> 5;
         const int region = nb / C, head0 = (nb - region * C) / D;      // 0 = Q, 1 = K, 2 = V
-        const int kt_bytes = NCH * 1024, rv = D == 16 ? 17 : 32, tile_bytes = kt_bytes + 4 * rv * 16;
+        const int kt_bytes = NCH * 1024, rv = D <= 16 ? D + 1 : 32, tile_bytes = kt_bytes + 4 * rv * 16;
         if (region < 2) {
           // Q / K: row-major tile [token][64 + 4], bias (and the softmax scale for Q) folded in on the way
           const float mulv = region == 0 ? p.pk_qscale : 1.0f;
@@ -322,16 +323,17 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
           // lane (hh = lane >> 5, token = lane & 31) owns components 16c + 8hh .. +7 of chunk c of every head
           const int tok = lane & 31, hh = lane >> 5;
           for (int hp = 0; hp < HPP; ++hp) {
-            const size_t bh_tile = (size_t)(b * 4 + head0 + hp) * p.pk_nt + tile;
+            const size_t bh_tile = (size_t)(b * nheads + head0 + hp) * p.pk_nt + tile;
             float nk = 0.f;
             for (int c = 0; c < NCH; ++c) {
               const float* src = ct + tok * BNP + hp * D + 16 * c + hh * 8;
-              const float4 a = *reinterpret_cast<const float4*>(src), e = *reinterpret_cast<const float4*>(src + 4);
+              float4 a = make_float4(0.f, 0.f, 0.f, 0.f), e = a;
+              if (16 * c + hh * 8 < D) { a = *reinterpret_cast<const float4*>(src); e = *reinterpret_cast<const float4*>(src + 4); }   // (head_dim 8: the upper half-chunk is padding)
               bf16x8 v;
               v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
               v[4] = (__bf16)e.x; v[5] = (__bf16)e.y; v[6] = (__bf16)e.z; v[7] = (__bf16)e.w;
-              if (region == 0) {         // Q[bh][token][D]
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.pk_q) + (bh_tile * 32 + tok) * D + 16 * c + hh * 8) = v;
+              if (region == 0) {         // Q[bh][token][DP]
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.pk_q) + (bh_tile * 32 + tok) * DPq + 16 * c + hh * 8) = v;
               } else {                   // K image: chunk c, lane l = hh*32 + key at byte c*1024 + l*16
                 *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(p.pk_kv) + bh_tile * tile_bytes + c * 1024 + lane * 16) = v;
 #pragma unroll
@@ -367,16 +369,16 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
             bf16x8 v;
             v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
             v[4] = (__bf16)e.x; v[5] = (__bf16)e.y; v[6] = (__bf16)e.z; v[7] = (__bf16)e.w;
-            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * 4 + head0 + hp) * p.pk_nt + tile) * tile_bytes + kt_bytes;
+            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * nheads + head0 + hp) * p.pk_nt + tile) * tile_bytes + kt_bytes;
             *reinterpret_cast<bf16x8*>(vb + (size_t)slab * rv * 16 + row * 16) = v;
           }
-          if (D == 16 && lane < 16) {   // the ones row (softmax denominator): row 16 of each (head, slab)
+          if (D <= 16 && lane < 4 * HPP) {   // the ones row (softmax denominator): row D of each (head, slab) of this pass
             bf16x8 one;
 #pragma unroll
             for (int j2 = 0; j2 < 8; ++j2) one[j2] = (__bf16)1.0f;
-            const int hd = lane >> 2, slab = lane & 3;
-            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * 4 + hd) * p.pk_nt + tile) * tile_bytes + kt_bytes;
-            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * rv * 16 + 16 * 16) = one;
+            const int hd = head0 + (lane >> 2), slab = lane & 3;
+            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * nheads + hd) * p.pk_nt + tile) * tile_bytes + kt_bytes;
+            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * rv * 16 + D * 16) = one;
           }
         }
         continue;
@@ -603,9 +605,10 @@ bool gemm16_supported(const IGemm& p) {
 
 void launch_gemm16(const IGemm& p, hipStream_t stream) {
   if (!gemm16_supported(p)) throw std::runtime_error("gemm16: unsupported operand layout");
-  if (p.pk_q && !((p.pk_D == 16 || p.pk_D == 32) && p.Cout == 12 * p.pk_D && p.taps == 1 && p.bias && p.pk_kv && p.pk_kmax &&
+  if (p.pk_q && !((p.pk_D == 8 || p.pk_D == 16 || p.pk_D == 32) && p.pk_heads > 0 && ((p.pk_heads * p.pk_D) % 64) == 0 &&
+                  p.Cout == 3 * p.pk_heads * p.pk_D && p.taps == 1 && p.bias && p.pk_kv && p.pk_kmax &&
                   ((p.H * p.W) % 32) == 0 && p.pk_nt * 32 == p.H * p.W && p.epi_act == ACT_NONE && !p.mul && !p.res && !p.tb))
-    throw std::runtime_error("gemm16: fused qkv packing needs 4 heads of head_dim 16 or 32, whole 32-token tiles, plain epilogue");
+    throw std::runtime_error("gemm16: fused qkv packing needs head_dim 8, 16 or 32 with heads * head_dim a multiple of 64, whole 32-token tiles, plain epilogue");
   if (p.Cinb && !(p.A16b && p.Wt16b && (p.Cinb % 8) == 0 && (p.lda16b % 8) == 0))
     throw std::runtime_error("gemm16: second K segment needs bf16 operands with channel counts that are multiples of 8");
   if (p.gn_sums) {

@@ -229,13 +229,13 @@ def test_attention_bf16(ops, N, C, heads):
     assert np.abs(got - ref).mean() < 4e-3
 
 
-@pytest.mark.parametrize("B,N,C", [(2, 256, 64), (1, 4096, 64), (3, 96 * 32, 64), (5, 64, 64),
-                                   (2, 256, 128), (1, 4096, 128), (3, 40 * 32, 128), (4, 64, 128)])
-def test_qkv_projection_fused_with_attention_packing(ops, B, N, C):
+@pytest.mark.parametrize("B,N,C,heads", [(2, 256, 64, 4), (1, 4096, 64, 4), (3, 96 * 32, 64, 4), (5, 64, 64, 4),
+                                         (2, 256, 128, 4), (1, 4096, 128, 4), (3, 40 * 32, 128, 4), (4, 64, 128, 4),
+                                         (2, 256, 64, 8), (1, 4096, 64, 8), (3, 40 * 32, 128, 8), (2, 1024, 256, 8), (5, 64, 64, 8)])
+def test_qkv_projection_fused_with_attention_packing(ops, B, N, C, heads):
     """in_proj whose epilogue writes the attention operand images (Q / K / V^T tiles, |k| bounds) must give exactly
     what the separate fp32-qkv + pack_qkv path gives (same GEMM, same roundings), and match nn.MultiheadAttention's
-    core (webp_inference.py:317-321) within bf16 operand precision.  head_dim 16 (C=64) and 32 (C=128)."""
-    heads = 4
+    core (webp_inference.py:317-321; 8 heads: avif_inference.py:281) within bf16 operand precision.  head_dim 8, 16 and 32."""
     x = rnd(B, N, C, seed=60, scale=1.2)
     w = rnd(3 * C, C, seed=61, scale=1.0 / np.sqrt(C)) * 1.5
     b = rnd(3 * C, seed=62, scale=0.3)
