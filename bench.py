@@ -187,7 +187,7 @@ def main():
         is_named = cfg_no is not None and (R, B, q, args.attn, args.dtype) == (256, 16, 10, "all", "bf16")
         codec_txt = ("device JPEG round trip (bit-exact to libjpeg-turbo)" if dev_codec else
                      "host Pillow/libjpeg-turbo callback" if args.arch == "jpeg" else
-                     ("library's lib%s C-API thread pool (bit-identical to Pillow), two pipelined micro-batch lanes" % args.arch
+                     ("library's lib%s C-API thread pool (bit-identical to Pillow), two pipelined micro-batch lanes (full-resolution blocks per lane, the levels below once per timestep)" % args.arch
                       if args.host_codec == "native" else "callback into Pillow (the reference's own calls), two pipelined micro-batch lanes"))
         line = {
             "metric": "restored images/sec (%dx%d, T=%d)" % (R, R, T), "value": value, "unit": "images/sec",
