@@ -48,6 +48,194 @@ __device__ __forceinline__ unsigned pack_e4m3x4(float4 v) {
   return (unsigned)r;
 }
 
+// Epilogue of the DMA GEMM kernels: split-K partial store, or accumulators -> wave-private LDS tile -> fused elementwise work
+// and row-contiguous stores (also the fused qkv packing and the GroupNorm statistics).  acc[nt][r] holds row
+// (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32 rows, column nt * 32 + lr.
+template <int NT>
+__device__ __forceinline__ void gemm16_epilogue(const IGemm& p, f32x16 (&acc)[NT], unsigned char* smem, int m0, int n0, int M, int HW,
+                                                int nsplit, int sk) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  // ------------------------------------------------------------------------------------------ epilogue
+  if ((GEMM_DBG(p) & 8) && acc[0][0] != 12345.f) return;
+  const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE || p.sel_C;
+  const bool atomic = nsplit > 1;
+  if (atomic) {
+    // split-K: raw partial sums to the workspace slice of this split (128-byte row segments per wave instruction); the
+    // linear epilogue runs in splitk_reduce_k, which adds the slices in a fixed order
+    float* ws = p.splitk_ws + (size_t)sk * M * p.Cout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= M) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + nt * 32 + lr;
+        if (n < p.Cout) ws[(size_t)m * p.Cout + n] = acc[nt][r];
+      }
+    }
+    return;
+  }
+  // coalesced: accumulators -> wave-private LDS tile (HN column tiles at a time) -> 16-byte row-contiguous accesses
+  constexpr int HN = NT < 2 ? NT : 2, BNH = HN * 32, BNP = BNH + 4;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                         // all waves are done reading the stage buffers
+  constexpr int CTW = (NT == 4 && 64 * 36 > 32 * BNP) ? 64 * 36 : 32 * BNP;   // floats per wave (the V^T pack pass stores its tile transposed)
+  float* ct = reinterpret_cast<float*>(smem) + wave * CTW;
+  constexpr int L4 = BNH / 4, RPP = 64 / L4;
+  const int c4 = lane % L4, rsub = lane / L4;
+  __bf16* out16 = reinterpret_cast<__bf16*>(p.out16);
+#pragma unroll
+  for (int h = 0; h < NT / HN; ++h) {
+    if constexpr (NT == 4) {
+      if (p.pk_q) {   // fused qkv projection: this 32-token x 64-column tile is Q, K or V of one 32-key attention tile
+        // `heads` heads of head_dim D = 8, 16 or 32 (C = heads * D, a multiple of 64); a 64-column pass holds 64/D heads of
+        // NCH 16-deep chunks each (head_dim 8 is zero-padded to one 16-deep chunk: AttnGeom<8>::DP = 16)
+        const int D = p.pk_D, nheads = p.pk_heads, C = nheads * D, NCH = D < 16 ? 1 : D >> 4, HPP = 64 / D, DPq = D < 16 ? 16 : D;
+        const int mrow0 = m0 + wave * 32, nb = n0 + h * BNH;
+        if (mrow0 >= M || nb >= 3 * C) continue;
+        const int b = mrow0 / HW, tile = (mrow0 - b * HW) >> 5;
+        const int region = nb / C, head0 = (nb - region * C) / D;      // 0 = Q, 1 = K, 2 = V
+        const int kt_bytes = NCH * 1024, rv = D <= 16 ? D + 1 : 32, tile_bytes = kt_bytes + 4 * rv * 16;
+        if (region < 2) {
+          // Q / K: row-major tile [token][64 + 4], bias (and the softmax scale for Q) folded in on the way
+          const float mulv = region == 0 ? p.pk_qscale : 1.0f;
+#pragma unroll
+          for (int q = 0; q < HN; ++q) {
+            const float bcol = p.bias[nb + q * 32 + lr];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + q * 32 + lr] = (acc[h * HN + q][r] + bcol) * mulv;
+          }
+          // lane (hh = lane >> 5, token = lane & 31) owns components 16c + 8hh .. +7 of chunk c of every head
+          const int tok = lane & 31, hh = lane >> 5;
+          for (int hp = 0; hp < HPP; ++hp) {
+            const size_t bh_tile = (size_t)(b * nheads + head0 + hp) * p.pk_nt + tile;
+            float nk = 0.f;
+            for (int c = 0; c < NCH; ++c) {
+              const float* src = ct + tok * BNP + hp * D + 16 * c + hh * 8;
+              float4 a = make_float4(0.f, 0.f, 0.f, 0.f), e = a;
+              if (16 * c + hh * 8 < D) { a = *reinterpret_cast<const float4*>(src); e = *reinterpret_cast<const float4*>(src + 4); }   // (head_dim 8: the upper half-chunk is padding)
+              bf16x8 v;
+              v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+              v[4] = (__bf16)e.x; v[5] = (__bf16)e.y; v[6] = (__bf16)e.z; v[7] = (__bf16)e.w;
+              if (region == 0) {         // Q[bh][token][DP]
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.pk_q) + (bh_tile * 32 + tok) * DPq + 16 * c + hh * 8) = v;
+              } else {                   // K image: chunk c, lane l = hh*32 + key at byte c*1024 + l*16
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(p.pk_kv) + bh_tile * tile_bytes + c * 1024 + lane * 16) = v;
+#pragma unroll
+                for (int j2 = 0; j2 < 8; ++j2) { const float f = (float)v[j2]; nk = fmaf(f, f, nk); }
+              }
+            }
+            if (region == 1) {           // tile max of |k| on the rounded values (bound of any score of this tile)
+              nk += __shfl_xor(nk, 32);
+#pragma unroll
+              for (int off = 16; off > 0; off >>= 1) nk = fmaxf(nk, __shfl_xor(nk, off));
+              if (lane == 0) p.pk_kmax[bh_tile] = sqrtf(nk) * 1.002f;
+            }
+          }
+        } else {
+          // V: TRANSPOSED tile [column][32 tokens + 4] so the 4 consecutive keys of a V^T slot group are one float4
+          constexpr int TP = 36;
+#pragma unroll
+          for (int q = 0; q < HN; ++q) {
+            const float bcol = p.bias[nb + q * 32 + lr];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+              *reinterpret_cast<float4*>(ct + (q * 32 + lr) * TP + 8 * g4 + 4 * lh) =
+                  make_float4(acc[h * HN + q][4 * g4] + bcol, acc[h * HN + q][4 * g4 + 1] + bcol,
+                              acc[h * HN + q][4 * g4 + 2] + bcol, acc[h * HN + q][4 * g4 + 3] + bcol);
+          }
+          // V^T image: slab (s, hh), row d, slot j = key (j&3) + 8*(2s + (j>>2)) + 4hh; 64 columns x 4 slabs = 4 items per lane
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int item = it * 64 + lane, col = item & 63, slab = item >> 6;      // col = head-in-pass * D + row
+            const int hp = col / D, row = col - hp * D, sI = slab >> 1, hh = slab & 1;
+            const float* src = ct + col * TP + 16 * sI + 4 * hh;
+            const float4 a = *reinterpret_cast<const float4*>(src), e = *reinterpret_cast<const float4*>(src + 8);
+            bf16x8 v;
+            v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+            v[4] = (__bf16)e.x; v[5] = (__bf16)e.y; v[6] = (__bf16)e.z; v[7] = (__bf16)e.w;
+            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * nheads + head0 + hp) * p.pk_nt + tile) * tile_bytes + kt_bytes;
+            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * rv * 16 + row * 16) = v;
+          }
+          if (D <= 16 && lane < 4 * HPP) {   // the ones row (softmax denominator): row D of each (head, slab) of this pass
+            bf16x8 one;
+#pragma unroll
+            for (int j2 = 0; j2 < 8; ++j2) one[j2] = (__bf16)1.0f;
+            const int hd = head0 + (lane >> 2), slab = lane & 3;
+            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * nheads + hd) * p.pk_nt + tile) * tile_bytes + kt_bytes;
+            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * rv * 16 + D * 16) = one;
+          }
+        }
+        continue;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < HN; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + q * 32 + lr] = acc[h * HN + q][r];
+    const int n = n0 + h * BNH + 4 * c4;
+    if (n >= p.Cout) continue;                          // Cout % 4 == 0: a float4 is all in or all out
+    const bool hi_cols = p.sel_C && n >= p.sel_C;       // sel_C % 64 == 0: a 64-column pass is all low or all high
+    const int no = hi_cols ? n - p.sel_C : n;           // column of mul / res / out
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+    float gs1 = 0.f, gs2 = 0.f;                         // GroupNorm statistics of this lane's 4 columns over its rows
+#pragma unroll 4
+    for (int pass = 0; pass < 32 / RPP; ++pass) {
+      const int row = pass * RPP + rsub;
+      const int m = m0 + wave * 32 + row;
+      if (m >= M) continue;
+      float4 v = *reinterpret_cast<const float4*>(ct + row * BNP + 4 * c4);
+      int b = 0, y = 0, x = 0;
+      if (need_pos) {
+        b = m / HW;
+        const int rem = m - b * HW;
+        y = rem / p.W;
+        x = rem - y * p.W;
+      }
+      if (p.sel_C && is_low_freq(y, x, p.H, p.W, p.bs, p.low) == hi_cols) continue;   // the other gate owns this pixel
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      if (p.tb) { float4 t = *reinterpret_cast<const float4*>(p.tb + (size_t)b * p.ldtb + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      if (p.epi_act != ACT_NONE) { v.x = act_apply(v.x, p.epi_act); v.y = act_apply(v.y, p.epi_act); v.z = act_apply(v.z, p.epi_act); v.w = act_apply(v.w, p.epi_act); }
+      if (p.mul) { float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + no); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+      if (p.rowscale && (!p.sel_C || hi_cols)) { const float rs = p.rowscale[b]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+      if (p.epi_mask != MASK_NONE) {
+        const bool lowp = is_low_freq(y, x, p.H, p.W, p.bs, p.low);
+        const bool keep = (p.epi_mask == MASK_LOW) ? lowp : !lowp;
+        if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + no); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      if (p.gn_sums) {
+        gs1 += (v.x + v.y) + (v.z + v.w);
+        gs2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+      if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + no) = v;
+      if (out16) {
+        bf16x4 o;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(out16 + (size_t)m * p.ldo16 + no) = o;
+      }
+      if (p.out8) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.out8) + (size_t)m * p.ldo8 + no) = pack_e4m3x4(v);
+    }
+    if (p.gn_sums) {
+      // the wave's 32 rows lie in one image (HW % 32 == 0); fold rows (lanes L4 apart), then the lanes of one group
+      const int cpg = p.Cout / p.gn_groups, lg = cpg / 4;             // lanes per group within a row segment
+#pragma unroll
+      for (int off = L4; off < 64; off <<= 1) { gs1 += __shfl_xor(gs1, off); gs2 += __shfl_xor(gs2, off); }
+      const int span = lg < L4 ? lg : L4;
+      for (int off = 1; off < span; off <<= 1) { gs1 += __shfl_xor(gs1, off); gs2 += __shfl_xor(gs2, off); }
+      if (rsub == 0 && (c4 % span) == 0) {
+        const int b = (m0 + wave * 32) / HW;
+        double* dst = p.gn_sums + (((size_t)b * GN_SUM_SLOTS + (blockIdx.x & (GN_SUM_SLOTS - 1))) * p.gn_groups + n / cpg) * 2;
+        atomicAdd(dst, (double)gs1);
+        atomicAdd(dst + 1, (double)gs2);
+      }
+    }
+  }
+}
+
 // BK = K elements per stage (64 or 32).  BK = 32 keeps the workgroup at 32 KiB of ring so four of them share one CU:
 // one workgroup's barrier waits, LDS-read latency and epilogue overlap the MFMAs of the others.
 // STAGES = 2 (double buffering, one stage in flight per workgroup): measured better than a 3-stage ring with two stages
@@ -269,184 +457,164 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] *= sc;
   }
-  // ------------------------------------------------------------------------------------------ epilogue
-  if ((GEMM_DBG(p) & 8) && acc[0][0] != 12345.f) return;
-  const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE || p.sel_C;
-  const bool atomic = nsplit > 1;
-  if (atomic) {
-    // split-K: raw partial sums to the workspace slice of this split (128-byte row segments per wave instruction); the
-    // linear epilogue runs in splitk_reduce_k, which adds the slices in a fixed order
-    float* ws = p.splitk_ws + (size_t)sk * M * p.Cout;
+  gemm16_epilogue<NT>(p, acc, smem, m0, n0, M, HW, nsplit, sk);
+}
+
+// 3x3 convs with few output channels (Cout <= 64: the full-resolution levels) are bound by the L2 -> LDS stream of their
+// operand tiles, not by the matrix pipe: per 128 x 64 tile and 64-channel tap the generic kernel moves 16 KiB of A + 8 KiB
+// of B for 128 * 64 * 64 MACs.  But the three taps of one kernel row read the SAME pixels shifted by one: a tile is 128
+// consecutive pixels in NHWC order, so tap dx is the A tile moved by one LDS row.  This kernel stages, per (32-channel
+// chunk, kernel row dy), ONE strip of 130 pixel rows (pixel m0 - 1 .. m0 + 128) and the three taps' weights, and reads the A
+// fragments of tap dx at row offset dx; lanes whose pixel sits on the left / right image border get a zero fragment for
+// dx = -1 / +1 (the shifted row belongs to the neighbouring image row there).  A traffic drops 3x (B unchanged): 216 KiB ->
+// 122 KiB per tile at Cin = 64.  Same accumulation order as the generic kernel at BK = 32 (chunk outer, taps 0..8 inner).
+template <int NT>
+__global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BK = 32, ROWB = 64, CPR = 4, RSH = 2, KS = 2, STAGES = 2;
+  constexpr int AR = BM + 8;                            // strip rows allocated (130 used): row r = pixel m0 - 1 + r
+  constexpr int A_BYTES = AR * ROWB;
+  constexpr int BROWS = 64;                             // weight rows per tap (>= NT * 32; 64 x 4 chunks = one slot per thread)
+  constexpr int BT_BYTES = BROWS * ROWB, STAGE = A_BYTES + 3 * BT_BYTES;
+  constexpr int AL = 3;                                 // 130 rows x 4 chunks = 520 slots: two full rounds + 8 threads
+  static_assert(NT * 32 <= BROWS, "strip kernel: Cout tile <= 64");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = p.B * p.H * p.W, HW = p.H * p.W;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);   // neighbouring tiles (shared halo rows) on one XCD
+  const int m0 = bx * BM, n0 = by * (NT * 32);
+  const int nck = (p.Cin + BK - 1) / BK;
+  const int nit_main = 3 * nck;
+  const int nit_all = nit_main + (p.Cinb + BK - 1) / BK;
+  const int nsplit = gridDim.z, sk = blockIdx.z;
+  const int it0 = (int)((long long)nit_all * sk / nsplit), it1 = (int)((long long)nit_all * (sk + 1) / nsplit);
+  const int nit = it1 - it0;
+  const __bf16* A16 = reinterpret_cast<const __bf16*>(p.A16);
+  const __bf16* W16 = reinterpret_cast<const __bf16*>(p.Wt16);
+  const __bf16* A16b = reinterpret_cast<const __bf16*>(p.A16b);
+  const __bf16* W16b = reinterpret_cast<const __bf16*>(p.Wt16b);
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zero16) +
+                              (((blockIdx.x + 3 * blockIdx.y + 5 * blockIdx.z) & 15) * 256 + tid) * 16;
+  const unsigned lds0 = (unsigned)(size_t)smem;
+
+  // A slots: s = j * 256 + tid -> strip row s / 4 (pixel m0 - 1 + row), chunk position s % 4
+  int a_y[AL], a_m[AL], a_chunk[AL];
+  bool a_use[AL], a_ok[AL];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= M) continue;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + nt * 32 + lr;
-        if (n < p.Cout) ws[(size_t)m * p.Cout + n] = acc[nt][r];
-      }
-    }
-    return;
+  for (int j = 0; j < AL; ++j) {
+    const int row = (j * 256 + tid) >> 2, pos = tid & 3;
+    const int m = m0 - 1 + row;
+    a_use[j] = row < BM + 2;
+    a_ok[j] = a_use[j] && m >= 0 && m < M;
+    const int mm = a_ok[j] ? m : 0;
+    const int b = mm / HW, rem = mm - b * HW;
+    a_y[j] = rem / p.W;
+    a_m[j] = mm;
+    a_chunk[j] = pos ^ ((row >> RSH) & (CPR - 1));
   }
-  // coalesced: accumulators -> wave-private LDS tile (HN column tiles at a time) -> 16-byte row-contiguous accesses
-  constexpr int HN = NT < 2 ? NT : 2, BNH = HN * 32, BNP = BNH + 4;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                         // all waves are done reading the stage buffers
-  constexpr int CTW = (NT == 4 && 64 * 36 > 32 * BNP) ? 64 * 36 : 32 * BNP;   // floats per wave (the V^T pack pass stores its tile transposed)
-  float* ct = reinterpret_cast<float*>(smem) + wave * CTW;
-  constexpr int L4 = BNH / 4, RPP = 64 / L4;
-  const int c4 = lane % L4, rsub = lane / L4;
-  __bf16* out16 = reinterpret_cast<__bf16*>(p.out16);
+  // B slots: slot j = tap dx = j - 1 of the current kernel row, weight row tid / 4, chunk position tid % 4
+  const int b_row = tid >> 2;
+  const int b_n = b_row < NT * 32 ? n0 + b_row : p.Cout;       // rows past the tile read the zero page
+  const int b_chunk = (tid & 3) ^ ((b_row >> RSH) & (CPR - 1));
+
+  auto issue = [&](int itl) {
+    const int it = it0 + itl;
+    const unsigned sb = lds0 + (itl % STAGES) * STAGE;
+    if (it >= nit_main) {   // second K segment (the block's 1x1 shortcut): centre position only
+      const int c0 = (it - nit_main) * BK;
 #pragma unroll
-  for (int h = 0; h < NT / HN; ++h) {
-    if constexpr (NT == 4) {
-      if (p.pk_q) {   // fused qkv projection: this 32-token x 64-column tile is Q, K or V of one 32-key attention tile
-        // `heads` heads of head_dim D = 8, 16 or 32 (C = heads * D, a multiple of 64); a 64-column pass holds 64/D heads of
-        // NCH 16-deep chunks each (head_dim 8 is zero-padded to one 16-deep chunk: AttnGeom<8>::DP = 16)
-        const int D = p.pk_D, nheads = p.pk_heads, C = nheads * D, NCH = D < 16 ? 1 : D >> 4, HPP = 64 / D, DPq = D < 16 ? 16 : D;
-        const int mrow0 = m0 + wave * 32, nb = n0 + h * BNH;
-        if (mrow0 >= M || nb >= 3 * C) continue;
-        const int b = mrow0 / HW, tile = (mrow0 - b * HW) >> 5;
-        const int region = nb / C, head0 = (nb - region * C) / D;      // 0 = Q, 1 = K, 2 = V
-        const int kt_bytes = NCH * 1024, rv = D <= 16 ? D + 1 : 32, tile_bytes = kt_bytes + 4 * rv * 16;
-        if (region < 2) {
-          // Q / K: row-major tile [token][64 + 4], bias (and the softmax scale for Q) folded in on the way
-          const float mulv = region == 0 ? p.pk_qscale : 1.0f;
-#pragma unroll
-          for (int q = 0; q < HN; ++q) {
-            const float bcol = p.bias[nb + q * 32 + lr];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + q * 32 + lr] = (acc[h * HN + q][r] + bcol) * mulv;
-          }
-          // lane (hh = lane >> 5, token = lane & 31) owns components 16c + 8hh .. +7 of chunk c of every head
-          const int tok = lane & 31, hh = lane >> 5;
-          for (int hp = 0; hp < HPP; ++hp) {
-            const size_t bh_tile = (size_t)(b * nheads + head0 + hp) * p.pk_nt + tile;
-            float nk = 0.f;
-            for (int c = 0; c < NCH; ++c) {
-              const float* src = ct + tok * BNP + hp * D + 16 * c + hh * 8;
-              float4 a = make_float4(0.f, 0.f, 0.f, 0.f), e = a;
-              if (16 * c + hh * 8 < D) { a = *reinterpret_cast<const float4*>(src); e = *reinterpret_cast<const float4*>(src + 4); }   // (head_dim 8: the upper half-chunk is padding)
-              bf16x8 v;
-              v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-              v[4] = (__bf16)e.x; v[5] = (__bf16)e.y; v[6] = (__bf16)e.z; v[7] = (__bf16)e.w;
-              if (region == 0) {         // Q[bh][token][DP]
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.pk_q) + (bh_tile * 32 + tok) * DPq + 16 * c + hh * 8) = v;
-              } else {                   // K image: chunk c, lane l = hh*32 + key at byte c*1024 + l*16
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(p.pk_kv) + bh_tile * tile_bytes + c * 1024 + lane * 16) = v;
-#pragma unroll
-                for (int j2 = 0; j2 < 8; ++j2) { const float f = (float)v[j2]; nk = fmaf(f, f, nk); }
-              }
-            }
-            if (region == 1) {           // tile max of |k| on the rounded values (bound of any score of this tile)
-              nk += __shfl_xor(nk, 32);
-#pragma unroll
-              for (int off = 16; off > 0; off >>= 1) nk = fmaxf(nk, __shfl_xor(nk, off));
-              if (lane == 0) p.pk_kmax[bh_tile] = sqrtf(nk) * 1.002f;
-            }
-          }
-        } else {
-          // V: TRANSPOSED tile [column][32 tokens + 4] so the 4 consecutive keys of a V^T slot group are one float4
-          constexpr int TP = 36;
-#pragma unroll
-          for (int q = 0; q < HN; ++q) {
-            const float bcol = p.bias[nb + q * 32 + lr];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-              *reinterpret_cast<float4*>(ct + (q * 32 + lr) * TP + 8 * g4 + 4 * lh) =
-                  make_float4(acc[h * HN + q][4 * g4] + bcol, acc[h * HN + q][4 * g4 + 1] + bcol,
-                              acc[h * HN + q][4 * g4 + 2] + bcol, acc[h * HN + q][4 * g4 + 3] + bcol);
-          }
-          // V^T image: slab (s, hh), row d, slot j = key (j&3) + 8*(2s + (j>>2)) + 4hh; 64 columns x 4 slabs = 4 items per lane
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int item = it * 64 + lane, col = item & 63, slab = item >> 6;      // col = head-in-pass * D + row
-            const int hp = col / D, row = col - hp * D, sI = slab >> 1, hh = slab & 1;
-            const float* src = ct + col * TP + 16 * sI + 4 * hh;
-            const float4 a = *reinterpret_cast<const float4*>(src), e = *reinterpret_cast<const float4*>(src + 8);
-            bf16x8 v;
-            v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-            v[4] = (__bf16)e.x; v[5] = (__bf16)e.y; v[6] = (__bf16)e.z; v[7] = (__bf16)e.w;
-            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * nheads + head0 + hp) * p.pk_nt + tile) * tile_bytes + kt_bytes;
-            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * rv * 16 + row * 16) = v;
-          }
-          if (D <= 16 && lane < 4 * HPP) {   // the ones row (softmax denominator): row D of each (head, slab) of this pass
-            bf16x8 one;
-#pragma unroll
-            for (int j2 = 0; j2 < 8; ++j2) one[j2] = (__bf16)1.0f;
-            const int hd = head0 + (lane >> 2), slab = lane & 3;
-            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * nheads + hd) * p.pk_nt + tile) * tile_bytes + kt_bytes;
-            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * rv * 16 + D * 16) = one;
-          }
-        }
-        continue;
+      for (int j = 0; j < AL; ++j) {
+        if (!a_use[j]) continue;
+        const int c = c0 + 8 * a_chunk[j];
+        const bool ok = a_ok[j] && c < p.Cinb;
+        const void* g = ok ? (const void*)(A16b + (size_t)a_m[j] * p.lda16b + c) : (const void*)zero;
+        __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sb + (j * 256 + wave * 64) * 16), 16, 0, 0);
       }
+      {
+        const int c = c0 + 8 * b_chunk;
+        const bool ok = b_n < p.Cout && c < p.Cinb;
+        const void* g = ok ? (const void*)(W16b + (size_t)b_n * p.Cinb + c) : (const void*)zero;
+        __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sb + A_BYTES + BT_BYTES + (wave * 64) * 16), 16, 0, 0);
+      }
+      return;
+    }
+    const int ck = it / 3, dyi = it - ck * 3, dy = dyi - 1, c0 = ck * BK;
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+      if (!a_use[j]) continue;
+      const int c = c0 + 8 * a_chunk[j];
+      const bool ok = a_ok[j] && c < p.Cin && (unsigned)(a_y[j] + dy) < (unsigned)p.H;
+      const void* g = ok ? (const void*)(A16 + ((ptrdiff_t)a_m[j] + (ptrdiff_t)dy * p.W) * p.lda16 + c) : (const void*)zero;
+      __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sb + (j * 256 + wave * 64) * 16), 16, 0, 0);
     }
 #pragma unroll
-    for (int q = 0; q < HN; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + q * 32 + lr] = acc[h * HN + q][r];
-    const int n = n0 + h * BNH + 4 * c4;
-    if (n >= p.Cout) continue;                          // Cout % 4 == 0: a float4 is all in or all out
-    const bool hi_cols = p.sel_C && n >= p.sel_C;       // sel_C % 64 == 0: a 64-column pass is all low or all high
-    const int no = hi_cols ? n - p.sel_C : n;           // column of mul / res / out
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
-    float gs1 = 0.f, gs2 = 0.f;                         // GroupNorm statistics of this lane's 4 columns over its rows
-#pragma unroll 4
-    for (int pass = 0; pass < 32 / RPP; ++pass) {
-      const int row = pass * RPP + rsub;
-      const int m = m0 + wave * 32 + row;
-      if (m >= M) continue;
-      float4 v = *reinterpret_cast<const float4*>(ct + row * BNP + 4 * c4);
-      int b = 0, y = 0, x = 0;
-      if (need_pos) {
-        b = m / HW;
-        const int rem = m - b * HW;
-        y = rem / p.W;
-        x = rem - y * p.W;
-      }
-      if (p.sel_C && is_low_freq(y, x, p.H, p.W, p.bs, p.low) == hi_cols) continue;   // the other gate owns this pixel
-      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-      if (p.tb) { float4 t = *reinterpret_cast<const float4*>(p.tb + (size_t)b * p.ldtb + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-      if (p.epi_act != ACT_NONE) { v.x = act_apply(v.x, p.epi_act); v.y = act_apply(v.y, p.epi_act); v.z = act_apply(v.z, p.epi_act); v.w = act_apply(v.w, p.epi_act); }
-      if (p.mul) { float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + no); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
-      if (p.rowscale && (!p.sel_C || hi_cols)) { const float rs = p.rowscale[b]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
-      if (p.epi_mask != MASK_NONE) {
-        const bool lowp = is_low_freq(y, x, p.H, p.W, p.bs, p.low);
-        const bool keep = (p.epi_mask == MASK_LOW) ? lowp : !lowp;
-        if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + no); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-      if (p.gn_sums) {
-        gs1 += (v.x + v.y) + (v.z + v.w);
-        gs2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-      }
-      if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + no) = v;
-      if (out16) {
-        bf16x4 o;
-        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(out16 + (size_t)m * p.ldo16 + no) = o;
-      }
-      if (p.out8) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.out8) + (size_t)m * p.ldo8 + no) = pack_e4m3x4(v);
+    for (int j = 0; j < 3; ++j) {
+      const int c = c0 + 8 * b_chunk;
+      const bool ok = b_n < p.Cout && c < p.Cin;
+      const void* g = ok ? (const void*)(W16 + ((size_t)(dyi * 3 + j) * p.Cout + b_n) * p.Cin + c) : (const void*)zero;
+      __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(sb + A_BYTES + j * BT_BYTES + (wave * 64) * 16), 16, 0, 0);
     }
-    if (p.gn_sums) {
-      // the wave's 32 rows lie in one image (HW % 32 == 0); fold rows (lanes L4 apart), then the lanes of one group
-      const int cpg = p.Cout / p.gn_groups, lg = cpg / 4;             // lanes per group within a row segment
+  };
+
+  f32x16 acc[NT];
 #pragma unroll
-      for (int off = L4; off < 64; off <<= 1) { gs1 += __shfl_xor(gs1, off); gs2 += __shfl_xor(gs2, off); }
-      const int span = lg < L4 ? lg : L4;
-      for (int off = 1; off < span; off <<= 1) { gs1 += __shfl_xor(gs1, off); gs2 += __shfl_xor(gs2, off); }
-      if (rsub == 0 && (c4 % span) == 0) {
-        const int b = (m0 + wave * 32) / HW;
-        double* dst = p.gn_sums + (((size_t)b * GN_SUM_SLOTS + (blockIdx.x & (GN_SUM_SLOTS - 1))) * p.gn_groups + n / cpg) * 2;
-        atomicAdd(dst, (double)gs1);
-        atomicAdd(dst + 1, (double)gs2);
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  const int arow = wave * 32 + lr;                      // the lane's pixel of the tile = strip row arow + 1
+  const int px = (m0 + arow) % p.W;                     // its column in the image: taps that leave the image row are zero
+  const bool x_ok[3] = {px > 0, true, px + 1 < p.W};
+  const int b_key = (lr >> RSH) & (CPR - 1);
+  bf16x8 zero8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) zero8[j] = (__bf16)0.f;
+
+  if (nit > 0) issue(0);
+  for (int it = 0; it < nit; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 1 < nit) issue(it + 1);
+    const unsigned char* st = smem + (it % STAGES) * STAGE;
+    const bool seg2 = it0 + it >= nit_main;
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi) {
+      if (seg2 && dxi != 1) continue;
+      const int row = arow + dxi, a_key = (row >> RSH) & (CPR - 1);
+      bf16x8 af[KS], bfr[KS][NT];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        af[ks] = *reinterpret_cast<const bf16x8*>(st + row * ROWB + (((2 * ks + lh) ^ a_key) << 4));
+        if (!seg2 && !x_ok[dxi]) af[ks] = zero8;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bfr[ks][nt] = *reinterpret_cast<const bf16x8*>(st + A_BYTES + dxi * BT_BYTES + (nt * 32 + lr) * ROWB + (((2 * ks + lh) ^ b_key) << 4));
       }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bfr[ks][nt], acc[nt], 0, 0, 0);
     }
   }
+  gemm16_epilogue<NT>(p, acc, smem, m0, n0, M, HW, nsplit, sk);
+}
+
+template <int NT>
+void launch_strip(const IGemm& p, int64_t M, hipStream_t stream) {
+  constexpr int STAGE = (BM + 8) * 64 + 3 * 64 * 64;
+  constexpr int HN = NT < 2 ? NT : 2;
+  constexpr int EPI = 4 * 32 * (HN * 32 + 4) * 4;
+  constexpr int LDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+  static PerDeviceOnce attr;
+  attr.run([] {
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+  });
+  const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
+  IGemm q = p;
+  q.nmajor = 0; q.tap_pack = 0;
+  hipLaunchKernelGGL((conv3x3_strip_kernel<NT>), dim3(gx, gy, 1), dim3(256), LDS, stream, q);
 }
 
 // out[m][n] = epilogue(sum_s ws[s][m][n]) (s ascending): bias, time bias, activation, factors, residual; optional bf16 / e4m3 copy
@@ -582,6 +750,13 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
       return;
     }
     throw std::runtime_error("gemm16: fp8 operands need Cout > 64");
+  }
+  if constexpr (NT <= 2) {
+    // full-resolution 3x3 convs with <= 64 output channels: one strip of pixel rows per kernel row serves its three taps
+    if (p.taps == 9 && tiles >= 256 && p.Cin >= 32 && !(p.taps == 9 && p.Cin == 8) && !p.pk_q && !exp_switch("DDPMIR_NO_STRIP") && !GEMM_DBG(p)) {
+      launch_strip<NT>(p, M, stream);
+      return;
+    }
   }
   if (bk64) launch_nt<NT, 64, 2>(p, M, stream);
   else launch_nt<NT, 32, 2>(p, M, stream);
