@@ -678,3 +678,26 @@ def test_large_nonsquare_forward_bf16_tracks_fp32(name, arch, models):
     # and each image comes out as it does alone (batch 2 -> 1 changes the attention grid and every GEMM's tiling)
     y1 = models(arch)(tt(x[1:]), tt(t[1:]), tt(t[1:]))
     assert torch.equal(y1, y32[1:])
+
+
+@pytest.mark.parametrize("name,arch", [("webp", spec.ARCH_WEBP), ("avif", spec.ARCH_AVIF)])
+def test_two_lane_loop_shares_the_levels_below_full_resolution(name, arch, models):
+    """Host-codec families: the loop runs down1 / up5 per lane and everything below once for both lanes (model.hip fwd_head /
+    fwd_mid / fwd_tail).  Images are independent, so a batch of 6 (lanes of 3) must equal its images restored alone or in
+    other groupings -- bit for bit in fp32 mode -- including across a phase-fix step and the final step."""
+    import torch
+    from ddpm_image_restoration_amd import harness
+    from ddpm_image_restoration_amd.sampler import SAMPLER_BY_ARCH
+    x0 = synth.synth_images(6, 64, seed=31)
+    y = harness.COMPRESS[arch](torch.from_numpy(x0), 10).cuda()
+    s32 = SAMPLER_BY_ARCH[arch](models(arch))
+    kw = dict(steps=7, seed=9)                          # i = 6 .. 0: phase fixes at i = 6, 3 (AVIF) / 5 (WebP), last step i = 0
+    full = s32.sample(y, 10, **kw)
+    parts = [s32.sample(y[a:b], 10, image_offset=a, **kw) for a, b in ((0, 2), (2, 3), (3, 6))]   # lanes of 1, no lanes, odd split
+    assert torch.equal(full, torch.cat(parts))
+    s16 = SAMPLER_BY_ARCH[arch](models(arch, dtype="bf16"))
+    f16 = s16.sample(y, 10, **kw)
+    assert torch.isfinite(f16).all()
+    # bf16 mode: same images through another grouping stay within the loop's bf16 scatter (GEMM tilings differ with the batch)
+    g16 = torch.cat([s16.sample(y[a:b], 10, image_offset=a, **kw) for a, b in ((0, 4), (4, 6))])
+    assert float((f16 - g16).abs().mean()) < 5e-2
