@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
   // profiles/r02_attn_nomax_headdim32_ab.txt): general kernel 2.77 ms, ones-MFMA 2.78, scalar adds 2.61 (QS = 2, 16 KiB
   // stages) -- 318 cycles per 1024 scores against the 199 of head_dim 16: with both pipes this full they overlap poorly.
   // N % 32 == 0 there (host check): without a ones row nothing masks the padding keys of a ragged last tile out of the sum.
-  static_assert(G::DT == 1 && G::KC <= 2, "no-max variant: head_dim <= 32");
+  static_assert(G::DT <= 2 && G::KC <= 4, "no-max variant: head_dim <= 64");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 stage buffers
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -546,13 +546,17 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
       qf[u][c] = *reinterpret_cast<const bf16x8*>(Qp + ((size_t)bh * NT * 32 + qr) * G::DP + 16 * c + 8 * lh);
   }
   constexpr bool LMFMA = !G::ONES && !SDEN;              // denominator: ones-operand MFMA tile, or (SDEN) scalar adds
-  f32x16 o[QS], lsum[LMFMA ? QS : 1];
+  f32x16 o[QS][G::DT], lsum[LMFMA ? QS : 1];
   float lacc[QS][2];
 #pragma unroll
   for (int u = 0; u < QS; ++u) {
     lacc[u][0] = lacc[u][1] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o[u][r] = 0.f; if (LMFMA) lsum[u][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt) o[u][dt][r] = 0.f;
+      if (LMFMA) lsum[u][r] = 0.f;
+    }
   }
   f32x16 zero16;
 #pragma unroll
@@ -583,20 +587,23 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
     if (st + 1 < nstages) dma(st + 1, buf ^ 1);
     const unsigned char* sb = lds + buf * SG::STAGE_BYTES;
     const int tiles_here = min(TS, NT - st * TS);
-    bf16x8 kA[G::KC], vA[2], kB[G::KC], vB[2];
-    auto fetch = [&](int t, bf16x8 (&k_)[G::KC], bf16x8 (&v_)[2]) {
+    bf16x8 kA[G::KC], vA[G::DT][2], kB[G::KC], vB[G::DT][2];
+    auto fetch = [&](int t, bf16x8 (&k_)[G::KC], bf16x8 (&v_)[G::DT][2]) {
       const unsigned char* tb = sb + t * G::TILE_BYTES;
 #pragma unroll
       for (int c = 0; c < G::KC; ++c) k_[c] = *reinterpret_cast<const bf16x8*>(tb + c * 1024 + lane * 16);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-        v_[s2] = *reinterpret_cast<const bf16x8*>(tb + G::KT_BYTES + (s2 * 2 + lh) * (G::RV * 16) + vrow * 16);
+      for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          v_[dt][s2] = *reinterpret_cast<const bf16x8*>(tb + G::KT_BYTES + ((dt * 2 + s2) * 2 + lh) * (G::RV * 16) + vrow * 16);
     };
-    auto process = [&](const bf16x8 (&kf)[G::KC], const bf16x8 (&vf)[2]) {
+    auto process = [&](const bf16x8 (&kf)[G::KC], const bf16x8 (&vf)[G::DT][2]) {
 #pragma unroll
       for (int u = 0; u < QS; ++u) {
         f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[u][0], zero16, 0, 0, 0);
-        if constexpr (G::KC == 2) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[u][1], s, 0, 0, 0);
+#pragma unroll
+        for (int c = 1; c < G::KC; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[u][c], s, 0, 0, 0);
         bf16x8 pb[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -604,8 +611,11 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
           if constexpr (!G::ONES && SDEN) lacc[u][r & 1] += pv;
           pb[r >> 3][r & 7] = (__bf16)pv;
         }
-        o[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb[0], o[u], 0, 0, 0);
-        o[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb[1], o[u], 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) {
+          o[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], pb[0], o[u][dt], 0, 0, 0);
+          o[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][1], pb[1], o[u][dt], 0, 0, 0);
+        }
         if constexpr (LMFMA) {
           lsum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[0], lsum[u], 0, 0, 0);
           lsum[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[1], lsum[u], 0, 0, 0);
@@ -627,7 +637,7 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
   for (int u = 0; u < QS; ++u) {
     // row D of O^T: register (D/8)*4 of lane half 0; or any row of the ones-operand tile (its column sums of P)
     float l;
-    if constexpr (G::ONES) l = __shfl(o[u][(D / 8) * 4], lr);
+    if constexpr (G::ONES) l = __shfl(o[u][0][(D / 8) * 4], lr);
     else if constexpr (LMFMA) l = lsum[LMFMA ? u : 0][0];
     else { l = lacc[u][0] + lacc[u][1]; l += __shfl_xor(l, 32); }   // the lane halves hold the two key halves of a query
     const float inv = 1.0f / l;
@@ -636,10 +646,12 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
       float* op = out + ((size_t)b * N + qr) * ldo + head * D;
       __bf16* op16 = out16 ? out16 + ((size_t)b * N + qr) * (size_t)(heads * D) + head * D : nullptr;
 #pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int dd = 8 * g + 4 * lh;
+        const int dd = 32 * dt + 8 * g + 4 * lh;
         if (dd < D) {
-          const float4 v = make_float4(o[u][4 * g] * inv, o[u][4 * g + 1] * inv, o[u][4 * g + 2] * inv, o[u][4 * g + 3] * inv);
+          const float4 v = make_float4(o[u][dt][4 * g] * inv, o[u][dt][4 * g + 1] * inv, o[u][dt][4 * g + 2] * inv, o[u][dt][4 * g + 3] * inv);
           if (op16) {
             typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
             bf16x4 w;
@@ -830,7 +842,11 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
       if ((N % 32) == 0) run_flash<32, 2, 8, 0, 1, 1, 4, 2, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16);
       else run_flash<32, 2, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16);
       break;
-    case 64: run_flash<64, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
+    case 64:   // bounded scores: no-max kernel (one query sub-tile per wave, 16 KiB stages, scalar-add denominators): 355 -> 269 us
+      // at N = 4096, B = 16; below N = 2048 its bounds pass and memset cost more than it saves
+      if ((N % 32) == 0 && N >= 2048) run_flash<64, 1, AttnGeom<64>::TS_DEFAULT, 0, 1, 0, 2, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16);
+      else run_flash<64, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16);
+      break;
     case 128: run_flash<128, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
     default: throw std::runtime_error("attention_bf16: unsupported head dim");
   }
