@@ -2,8 +2,9 @@
 // webp_inference.py:295,317-321; 95 % of the FLOPs at 256^2 sit in the two full-resolution blocks with
 // N = 65 536 tokens and head_dim 16, where the kernel is bound by v_exp_f32 issue, not by MFMA).
 //
-// Two kernels:
-//  pack_qkv_bf16<D>   fp32 qkv [B][N][3C]  ->  bf16 operand images laid out exactly as the wave reads them:
+// Kernels:
+//  pack_qkv_bf16<D>   fp32 qkv [B][N][3C]  ->  bf16 operand images laid out exactly as the wave reads them
+//                     (head_dim 8 / 16 / 32 with C a multiple of 64: written by the in_proj GEMM's epilogue instead, gemm16.hip):
 //      Qp [bh][Npad][DP]                       q * log2(e)/sqrt(d), d zero-padded to DP (multiple of 16)
 //      Kp [bh][tile][c][h][32 keys][8]         one 16-deep k chunk c, lane half h: lane l reads 16 B at l*16
 //      Vp [bh][tile][dt][s][h][rows][8]        V transposed AND key-permuted: slot j of lane half h at MFMA step s
@@ -17,10 +18,12 @@
 //      The running max is only raised when a tile exceeds it by more than RESCALE_THR (deferred rescale;
 //      fp32 accumulators and bf16's 8-bit exponent make 2^THR-sized p harmless), so the per-tile VALU work
 //      is 16 v_exp + 8 v_max3 + 8 v_cvt_pk per 1024 scores.
-//  K/V stream through LDS in stages of several 32-key tiles (double buffered, register-staged: loads for
-//  stage i+1 are issued before the MFMAs of stage i, written to LDS after), laid out so every LDS read is
-//  a linear 1 KiB wave read (conflict-free).  Workgroups of one (batch, head) are placed on one XCD so the
-//  4 MiB of K/V they all re-read stay in that XCD's L2.
+//  flash_bf16_nm<D,QS,TS>  the same without a running max (and without its registers: three waves per SIMD) for the
+//      (batch, head) pairs whose scores are provably bounded (attn_pair_bounds_k: max|q| * max|k| <= NM_BOUND in log2
+//      units); head_dim <= 64.  The general kernel skips those pairs.
+//  K/V stream through LDS in stages of several 32-key tiles, double buffered, filled by global_load_lds (the packed
+//  images are a linear copy), laid out so every LDS read is a linear 1 KiB wave read (conflict-free).  Workgroups of one
+//  (batch, head) are placed on one XCD so the 4 MiB of K/V they all re-read stay in that XCD's L2.
 #include <cstdlib>
 #include <stdexcept>
 

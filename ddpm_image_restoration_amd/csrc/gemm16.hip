@@ -4,8 +4,11 @@
 //
 // A16 is a bf16 NHWC tensor that already contains what the GEMM consumes (normalised / activated / masked by
 // the producing kernel), so nothing has to pass through VGPRs on the way in: every wave issues 16-byte-per-lane
-// direct-to-LDS loads for a 3-stage ring and only waits with a counted vmcnt -- the loads of two K chunks stay
-// in flight across the barrier while the MFMAs of the current chunk run.
+// direct-to-LDS loads into a stage ring -- two stages in production: the next K chunk is in flight across the raw
+// s_barrier while the MFMAs of the current chunk run, and three or four workgroups per CU hide each other's waits
+// (a three-stage ring with a counted vmcnt is still instantiable: it lost to the smaller footprint).
+// Kernels: gemm16_kernel (generic: 1x1 / 3x3, optional second K segment, fp8 operands, split-K),
+// conv3x3_strip_kernel (3x3 with <= 64 output channels at the large levels), one shared epilogue (gemm16_epilogue).
 //
 // LDS image per stage: A [128 rows][BK] bf16, B [32*NT rows][BK] bf16, unpadded rows of BK*2 bytes (BK = 32 or 64).
 // A DMA wave-instruction writes 64 lanes x 16 B linearly, so the bank-conflict fix is an XOR swizzle on the SOURCE
