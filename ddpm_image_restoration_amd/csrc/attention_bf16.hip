@@ -476,14 +476,20 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
 // bounds[bh] = { max |q|^2 , max |k| } of a (batch, head) pair as fp32 bit patterns (non-negative floats order like
 // unsigned integers, so partial maxima fold with atomicMax).  Norms of the bf16 operands as the MFMA sees them; q carries
 // log2(e)/sqrt(d); the per-tile |k| bounds come from the packers.  Grid (slices, pairs); cleared by a memset node before.
+// Qmax2 != null: the producer of the operand images (the fused qkv projection) left the per-tile max |q|^2 there, so the
+// 134 MB of Q are not read again.  One slice per pair stores its result (no memset, no atomics).
 template <int DP>
 __global__ __launch_bounds__(256) void attn_pair_bounds_k(const __bf16* __restrict__ Qp, const float* __restrict__ Kmax, int NT,
-                                                          PairBounds* __restrict__ bounds) {
+                                                          PairBounds* __restrict__ bounds, const float* __restrict__ Qmax2) {
   __shared__ float rq[4], rk[4];
   const int bh = blockIdx.y, tid = threadIdx.x, nsl = gridDim.x, sl = blockIdx.x;
   const __bf16* q = Qp + (size_t)bh * NT * 32 * DP;
   const int rows = NT * 32, r0 = (int)((long long)rows * sl / nsl), r1 = (int)((long long)rows * (sl + 1) / nsl);
   float m = 0.f;
+  if (Qmax2) {
+    const int u0 = (int)((long long)NT * sl / nsl), u1 = (int)((long long)NT * (sl + 1) / nsl);
+    for (int t = u0 + tid; t < u1; t += 256) m = fmaxf(m, Qmax2[(size_t)bh * NT + t]);
+  } else
   for (int r = r0 + tid; r < r1; r += 256) {
     float ss = 0.f;
 #pragma unroll
@@ -505,8 +511,11 @@ __global__ __launch_bounds__(256) void attn_pair_bounds_k(const __bf16* __restri
     m = fmaxf(fmaxf(rq[0], rq[1]), fmaxf(rq[2], rq[3]));
     km = fmaxf(fmaxf(rk[0], rk[1]), fmaxf(rk[2], rk[3]));
     if (!(m == m) || !(km == km)) { m = INFINITY; km = INFINITY; }          // NaN operands: route to the general kernel
-    atomicMax(&bounds[bh].qmax2, __float_as_uint(m));
-    atomicMax(&bounds[bh].kmax, __float_as_uint(km));
+    if (nsl == 1) { bounds[bh].qmax2 = __float_as_uint(m); bounds[bh].kmax = __float_as_uint(km); }
+    else {
+      atomicMax(&bounds[bh].qmax2, __float_as_uint(m));
+      atomicMax(&bounds[bh].kmax, __float_as_uint(km));
+    }
   }
 }
 
@@ -694,8 +703,10 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
     // pairs with bounded scores run without a running max (three waves per SIMD); the general kernel takes the rest
     using SN = StageGeom<D, NMTS>;
     PairBounds* flags = reinterpret_cast<PairBounds*>(Kmax + (size_t)BH * NT);
-    DDPMIR_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)BH * sizeof(PairBounds), s));
-    hipLaunchKernelGGL(attn_pair_bounds_k<G::DP>, dim3(NT >= 256 ? 32 : 1, BH), dim3(256), 0, s, (const __bf16*)Qp, (const float*)Kmax, NT, flags);
+    const float* Qmax2 = qkv ? nullptr : reinterpret_cast<const float*>(flags + BH);   // written by the fused projection (pack targets)
+    const int nsl = (!Qmax2 && NT >= 256) ? 32 : 1;
+    if (nsl > 1) DDPMIR_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)BH * sizeof(PairBounds), s));
+    hipLaunchKernelGGL(attn_pair_bounds_k<G::DP>, dim3(nsl, BH), dim3(256), 0, s, (const __bf16*)Qp, (const float*)Kmax, NT, flags, Qmax2);
     static PerDeviceOnce attr_nm;
     attr_nm.run([] {
       DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16_nm<D, NMQS, NMTS, NMSD>),
@@ -716,7 +727,7 @@ size_t ws_bytes_for(int B, int N, int heads) {
   using G = AttnGeom<D>;
   const size_t NT = (N + 31) / 32, BH = (size_t)B * heads;
   return ((BH * NT * 32 * G::DP * 2 + 255) & ~size_t(255)) + ((BH * NT * G::TILE_BYTES + 255) & ~size_t(255)) +
-         BH * NT * 4 + BH * 8 + 256;   // ... + per-tile |k| bounds + the score bounds of every (batch, head) pair
+         BH * NT * 4 + BH * 8 + BH * NT * 4 + 256;   // ... + per-tile |k| bounds + the pairs' score bounds + per-tile max |q|^2
 }
 
 }  // namespace
@@ -744,6 +755,7 @@ static AttnPack16 pack_targets_for(int B, int N, int heads, void* ws) {   // sam
   t.q = ws;
   t.kv = static_cast<unsigned char*>(ws) + q_bytes;
   t.kmax = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + q_bytes + kv_bytes);
+  t.qmax2 = reinterpret_cast<float*>(reinterpret_cast<PairBounds*>(t.kmax + BH * NT) + BH);   // behind the pairs' bounds (run_flash)
   t.ntiles = (int)NT;
   t.qscale = 1.44269504088896340736f / sqrtf((float)D);
   t.D = D;

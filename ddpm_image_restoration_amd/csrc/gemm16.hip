@@ -126,15 +126,21 @@ __device__ __forceinline__ void gemm16_epilogue(const IGemm& p, f32x16 (&acc)[NT
                 *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.pk_q) + (bh_tile * 32 + tok) * DPq + 16 * c + hh * 8) = v;
               } else {                   // K image: chunk c, lane l = hh*32 + key at byte c*1024 + l*16
                 *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(p.pk_kv) + bh_tile * tile_bytes + c * 1024 + lane * 16) = v;
-#pragma unroll
-                for (int j2 = 0; j2 < 8; ++j2) { const float f = (float)v[j2]; nk = fmaf(f, f, nk); }
               }
+#pragma unroll
+              for (int j2 = 0; j2 < 8; ++j2) { const float f = (float)v[j2]; nk = fmaf(f, f, nk); }   // |q|^2 or |k|^2 of this token
             }
             if (region == 1) {           // tile max of |k| on the rounded values (bound of any score of this tile)
               nk += __shfl_xor(nk, 32);
 #pragma unroll
               for (int off = 16; off > 0; off >>= 1) nk = fmaxf(nk, __shfl_xor(nk, off));
               if (lane == 0) p.pk_kmax[bh_tile] = sqrtf(nk) * 1.002f;
+            } else {                     // tile max of |q|^2 (scaled, rounded): attn_pair_bounds_k folds the tiles; NaN -> +inf
+              nk += __shfl_xor(nk, 32);
+              if (!(nk == nk)) nk = INFINITY;
+#pragma unroll
+              for (int off = 16; off > 0; off >>= 1) nk = fmaxf(nk, __shfl_xor(nk, off));
+              if (lane == 0) p.pk_qmax[bh_tile] = nk;
             }
           }
         } else {
@@ -784,7 +790,7 @@ bool gemm16_supported(const IGemm& p) {
 void launch_gemm16(const IGemm& p, hipStream_t stream) {
   if (!gemm16_supported(p)) throw std::runtime_error("gemm16: unsupported operand layout");
   if (p.pk_q && !((p.pk_D == 8 || p.pk_D == 16 || p.pk_D == 32) && p.pk_heads > 0 && ((p.pk_heads * p.pk_D) % 64) == 0 &&
-                  p.Cout == 3 * p.pk_heads * p.pk_D && p.taps == 1 && p.bias && p.pk_kv && p.pk_kmax &&
+                  p.Cout == 3 * p.pk_heads * p.pk_D && p.taps == 1 && p.bias && p.pk_kv && p.pk_kmax && p.pk_qmax &&
                   ((p.H * p.W) % 32) == 0 && p.pk_nt * 32 == p.H * p.W && p.epi_act == ACT_NONE && !p.mul && !p.res && !p.tb))
     throw std::runtime_error("gemm16: fused qkv packing needs head_dim 8, 16 or 32 with heads * head_dim a multiple of 64, whole 32-token tiles, plain epilogue");
   if (p.Cinb && !(p.A16b && p.Wt16b && (p.Cinb % 8) == 0 && (p.lda16b % 8) == 0))

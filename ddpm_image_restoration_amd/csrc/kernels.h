@@ -56,6 +56,7 @@ struct IGemm {
   // K axis of 72 (a 16-byte chunk = one tap), two K stages instead of nine mostly-zero ones
   int tap_pack = 0;
   void* pk_q = nullptr; void* pk_kv = nullptr; float* pk_kmax = nullptr; int pk_nt = 0; float pk_qscale = 0.f; int pk_D = 16; int pk_heads = 4;
+  float* pk_qmax = nullptr;                   // [bh][tile] max |q|^2 of the tile's 32 tokens (the score bound of the no-max attention kernel)
   // split-K partial sums [nsplit][M][Cout] fp32 (gemm16.hip): written by the splits, folded in fixed order by a second
   // kernel together with bias / time bias / residual / bf16 copy -> bf16 mode is bit-reproducible (no float atomics)
   float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;
@@ -95,7 +96,7 @@ bool attention_bf16_supported(int N, int C, int heads);
 // Operand images of the head_dim-16 attention kernel inside `workspace`, for producers that write them directly
 // (the fused qkv projection).  Tile = 32 keys: K image 1024 B + V^T image (2 x 2 slabs of 17 rows x 16 B).
 constexpr int ATTN16_KT_BYTES = 1024, ATTN16_RV = 17, ATTN16_TILE_BYTES = ATTN16_KT_BYTES + 4 * ATTN16_RV * 16;
-struct AttnPack16 { void* q; void* kv; float* kmax; int ntiles; float qscale; int D; int heads; };
+struct AttnPack16 { void* q; void* kv; float* kmax; int ntiles; float qscale; int D; int heads; float* qmax2; };
 bool attention_bf16_prepack_supported(int N, int C, int heads);
 AttnPack16 attention_bf16_pack_targets(int B, int N, int C, int heads, void* workspace);
 size_t attention_bf16_workspace(int B, int N, int C, int heads);

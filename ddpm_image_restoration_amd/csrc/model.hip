@@ -681,7 +681,7 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
     IGemm q = g; q.A16 = p.hB16; q.lda16 = C;
     if (prepack) {
       const AttnPack16 t = attention_bf16_pack_targets(B, HW, C, k.heads, p.attn_ws);
-      q.pk_q = t.q; q.pk_kv = t.kv; q.pk_kmax = t.kmax; q.pk_nt = t.ntiles; q.pk_qscale = t.qscale; q.pk_D = t.D; q.pk_heads = t.heads;
+      q.pk_q = t.q; q.pk_kv = t.kv; q.pk_kmax = t.kmax; q.pk_nt = t.ntiles; q.pk_qscale = t.qscale; q.pk_D = t.D; q.pk_heads = t.heads; q.pk_qmax = t.qmax2;
     } else {
       q.out = p.qkv; q.ldo = 3 * C;
     }

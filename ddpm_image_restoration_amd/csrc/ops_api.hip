@@ -327,7 +327,7 @@ int ddpmir_op_qkv_attention_bf16(const float* x, int B, int N, int C, int heads,
     float* qkv = nullptr;
     if (fused) {
       const AttnPack16 t = attention_bf16_pack_targets(B, N, C, heads, ws);
-      p.pk_q = t.q; p.pk_kv = t.kv; p.pk_kmax = t.kmax; p.pk_nt = t.ntiles; p.pk_qscale = t.qscale; p.pk_D = t.D; p.pk_heads = t.heads;
+      p.pk_q = t.q; p.pk_kv = t.kv; p.pk_kmax = t.kmax; p.pk_nt = t.ntiles; p.pk_qscale = t.qscale; p.pk_D = t.D; p.pk_heads = t.heads; p.pk_qmax = t.qmax2;
     } else {
       qkv = d.alloc<float>(M * 3 * C);
       p.out = qkv; p.ldo = 3 * C;
