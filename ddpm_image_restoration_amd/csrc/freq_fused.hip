@@ -8,7 +8,7 @@
 //
 // The three-kernel path (block_transform_fast_k, two gemm16 launches) moves, per pixel and channel, 4 + 4 + 2 bytes for the
 // DCT, 2 + 2 for the first layer and 2 + 4 + 4 + 2 for the second = 26 bytes; this kernel reads x once and writes S once
-// (6 bytes): at 256 x 256, B = 16, C = 64 that is 1.74 GB -> 0.40 GB per block and 490 us -> 172 us (DESIGN.md section 4.5).
+// (6 bytes): at 256 x 256, B = 16, C = 64 that is 1.74 GB -> 0.40 GB per block and 490 us -> 172 us (DESIGN.md section 4.4).
 // Arithmetic is the same instruction sequence as the kernels it replaces (DCT FMAs in the same order, MFMA k-steps in the
 // same order, the same roundings to bf16), so S comes out bit-identical (tests/test_gpu_ops.py).
 //
