@@ -50,6 +50,7 @@ SYMBOLS = {
     "ddpmir_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_double)]),
     "ddpmir_version": (C.c_char_p, []),
+    "ddpmir_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
 }
 
 _lib = None

@@ -18,6 +18,30 @@ NO_CONTRACT = {"sampler_kernels.hip"}   # bit-exact uint8 truncation path: no fm
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
+def source_hash() -> str:
+    """sha256/16 over csrc/* and include/*.h (names + contents, sorted): what ddpmir_version() of a fresh build reports."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    files += [os.path.join(HERE, "..", "include", f) for f in ("ddpmir.h", "ddpmir_ops.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _hipcc_version(hipcc: str) -> str:
+    try:
+        out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+        for ln in out.splitlines():
+            if "HIP version" in ln:
+                return ln.split(":", 1)[1].strip().replace(" ", "")
+    except Exception:
+        pass
+    return "unknown"
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -48,10 +72,18 @@ def _build(lib: str, objdir: str, defines, verbose: bool) -> str:
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []
+    # incremental: an object is kept while it is newer than its source, every header and this script
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs += [os.path.join(HERE, "..", "include", f) for f in ("ddpmir.h", "ddpmir_ops.h")] + [os.path.abspath(__file__)]
+    t_hdr = max(os.path.getmtime(h) for h in hdrs)
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
+        if src != "api.hip" and os.path.exists(obj) and os.path.getmtime(obj) > max(t_hdr, os.path.getmtime(os.path.join(CSRC, src))):
+            continue
         extra = ["-ffp-contract=off"] if src in NO_CONTRACT else []
+        if src == "api.hip":   # ddpmir_version(): source hash + compiler version, so a stale prebuilt binary is detectable
+            extra += ['-DDDPMIR_SRC_HASH="%s"' % source_hash(), '-DDDPMIR_HIPCC_VERSION="%s"' % _hipcc_version(hipcc)]
         if src in VGPR_MFMA:
             extra += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
         if src in NO_SLP:

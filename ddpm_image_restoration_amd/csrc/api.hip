@@ -187,7 +187,20 @@ int ddpmir_profile_read(ddpmir_ctx* ctx, const char* cls, double* ms, int64_t* l
   });
 }
 
-const char* ddpmir_version(void) { return "ddpmir 0.1.0 (gfx950)"; }
+#ifndef DDPMIR_SRC_HASH
+#define DDPMIR_SRC_HASH "unknown"
+#endif
+#ifndef DDPMIR_HIPCC_VERSION
+#define DDPMIR_HIPCC_VERSION "unknown"
+#endif
+const char* ddpmir_version(void) { return "ddpmir 0.3.0 (gfx950) src=" DDPMIR_SRC_HASH " hipcc=" DDPMIR_HIPCC_VERSION; }
+
+int ddpmir_set_option(ddpmir_ctx* ctx, const char* name, double value) {
+  return guarded(ctx, [&] {
+    if (!name) throw std::invalid_argument("set_option: null name");
+    ctx->impl->set_option(name, value);
+  });
+}
 
 }  // extern "C"
 

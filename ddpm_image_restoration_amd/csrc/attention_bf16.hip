@@ -131,14 +131,27 @@ __global__ __launch_bounds__(256) void pack_qkv_bf16(const float* __restrict__ q
 
 // ------------------------------------------------------------------------------------------------ flash
 constexpr float RESCALE_THR = 20.0f;   // log2 units
-// score bound of a (batch, head) pair below which the softmax needs no running max (flash_bf16_nm, further down)
-constexpr float NM_BOUND = 80.0f;      // log2 units
+// (the score bound below which the softmax needs no running max, flash_bf16_nm further down, is AttnOpts::nm_bound: 80 in log2 units)
 struct PairBounds { unsigned qmax2, kmax; };   // fp32 bit patterns of max |q|^2 and max |k|
-__device__ __forceinline__ bool pair_is_bounded(const PairBounds* bounds, int bh) {
-  const float q2 = __uint_as_float(bounds[bh].qmax2), km = __uint_as_float(bounds[bh].kmax);
-  return sqrtf(q2) * 1.002f * km <= NM_BOUND;
+// Routing is per (pair, ROUTING BLOCK of queries): a block of RB = 128 * NMQS consecutive queries (one workgroup of the no-max
+// kernel) runs without a running max when  max|q| of ITS queries * max|k| of the pair <= nm_bound  -- one outlier query token
+// sends its own block to the general kernel, not the pair's 65 536 queries.  blkq[bh][rb] = max |q|^2 of the block.
+__device__ __forceinline__ bool block_is_bounded(const PairBounds* bounds, const float* blkq, int bh, int nrb, int rb, float nm_bound) {
+  const float q2 = blkq[(size_t)bh * nrb + rb], km = __uint_as_float(bounds[bh].kmax);
+  return sqrtf(q2) * 1.002f * km <= nm_bound;
 }
 
+// Row of the V^T slab a lane reads as its A-operand row.  Rows 0 .. D-1 are V^T, row D the ones row (head_dim <= 16).
+// head_dim 16: ds_read_b128 is served in the lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} (+32): the ones row sits one
+// 256-byte bank row above row 0, so with lanes 16-31 ALL on it the first group holds rows 0-3 and row 16 on the same banks
+// (2-way: SQ_LDS_BANK_CONFLICT was 25 % of the LDS cycles of this kernel).  Only A row 16 must be the ones row (rows 17-31
+// of O^T are never read), so lanes 17-31 re-read rows 1-15: every group then covers 16 distinct 16-byte slots.
+template <int D, bool ONES>
+__device__ __forceinline__ int vt_row(int lr) {
+  if (!ONES) return lr;
+  if (D == 16) return lr <= 16 ? lr : lr - 16;
+  return lr < D ? lr : D;
+}
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -162,7 +175,9 @@ template <int D, int QS, int TS, int WPS = 0, int DMA = 1, int DEN = 0>
 __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
                                                   const float* __restrict__ Kmax, float* __restrict__ out, int ldo,
                                                   int N, int NT, int heads, int nqb, int npairs,
-                                                  __bf16* __restrict__ out16, const PairBounds* __restrict__ skip) {
+                                                  __bf16* __restrict__ out16, const PairBounds* __restrict__ skip,
+                                                  const float* __restrict__ blkq, int nrb, int rbq, float nm_bound,
+                                                  unsigned* __restrict__ taken) {
   using G = AttnGeom<D>;
   using SG = StageGeom<D, TS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 stage buffers
@@ -181,7 +196,9 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
     bh = wg / nqb;
     qb = wg - bh * nqb;
   }
-  if (skip && pair_is_bounded(skip, bh)) return;        // bounded scores: this pair ran in the no-max kernel (flash_bf16_nm)
+  // bounded scores: this query block ran in the no-max kernel (flash_bf16_nm); rbq = general workgroups per routing block
+  if (skip && block_is_bounded(skip, blkq, bh, nrb, qb / rbq, nm_bound)) return;
+  if (skip && taken && tid == 0) atomicAdd(taken, 1u);   // profiling: workgroups that needed the running max
   const int b = bh / heads, head = bh - b * heads;
   const int q0 = qb * (128 * QS) + wave * (32 * QS);
 
@@ -237,7 +254,7 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
   const unsigned char* gkv = KVp + (size_t)bh * NT * G::TILE_BYTES;
   const int nstages = (NT + TS - 1) / TS;
   const size_t total_bytes = (size_t)NT * G::TILE_BYTES;
-  const int vrow = G::ONES ? (lr < D ? lr : D) : lr;     // row of the V^T slab this lane reads
+  const int vrow = vt_row<D, G::ONES>(lr);               // row of the V^T slab this lane reads
 
   float* kmax_lds = reinterpret_cast<float*>(lds + 2 * SG::STAGE_BYTES);   // [2][TS]
   const float* gkmax = Kmax + (size_t)bh * NT;
@@ -473,47 +490,67 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void flash_bf16(const __b
 // the kernel fits three waves per SIMD (the general kernel: 229 VGPRs, two).  The pair's score bound (attn_pair_bounds_k) routes
 // each pair to exactly one of the two kernels; both are always launched and the workgroups of the other one return at once.
 
-// bounds[bh] = { max |q|^2 , max |k| } of a (batch, head) pair as fp32 bit patterns (non-negative floats order like
-// unsigned integers, so partial maxima fold with atomicMax).  Norms of the bf16 operands as the MFMA sees them; q carries
-// log2(e)/sqrt(d); the per-tile |k| bounds come from the packers.  Grid (slices, pairs); cleared by a memset node before.
+// bounds[bh].kmax = max |k| of a (batch, head) pair, blkq[bh][rb] = max |q|^2 of routing block rb (tpr 32-query tiles),
+// bounds[bh].qmax2 = max |q|^2 of the pair -- fp32 bit patterns (non-negative floats order like unsigned integers, so the
+// slices of a pair fold with atomicMax).  Norms of the bf16 operands as the MFMA sees them; q carries log2(e)/sqrt(d); the
+// per-tile |k| bounds come from the packers.  Grid (slices, pairs); with more than one slice a memset node clears bounds[].
 // Qmax2 != null: the producer of the operand images (the fused qkv projection) left the per-tile max |q|^2 there, so the
-// 134 MB of Q are not read again.  One slice per pair stores its result (no memset, no atomics).
+// 134 MB of Q are not read again and one workgroup per pair folds 2 x NT floats (no memset, no atomics).
 template <int DP>
-__global__ __launch_bounds__(256) void attn_pair_bounds_k(const __bf16* __restrict__ Qp, const float* __restrict__ Kmax, int NT,
-                                                          PairBounds* __restrict__ bounds, const float* __restrict__ Qmax2) {
+__global__ __launch_bounds__(256) void attn_block_bounds_k(const __bf16* __restrict__ Qp, const float* __restrict__ Kmax, int NT,
+                                                           int tpr, int nrb, PairBounds* __restrict__ bounds,
+                                                           float* __restrict__ blkq, const float* __restrict__ Qmax2) {
   __shared__ float rq[4], rk[4];
   const int bh = blockIdx.y, tid = threadIdx.x, nsl = gridDim.x, sl = blockIdx.x;
-  const __bf16* q = Qp + (size_t)bh * NT * 32 * DP;
-  const int rows = NT * 32, r0 = (int)((long long)rows * sl / nsl), r1 = (int)((long long)rows * (sl + 1) / nsl);
-  float m = 0.f;
+  const int rb0 = (int)((long long)nrb * sl / nsl), rb1 = (int)((long long)nrb * (sl + 1) / nsl);
+  float pm = 0.f;                                    // max |q|^2 over this slice's blocks (for bounds[].qmax2)
   if (Qmax2) {
-    const int u0 = (int)((long long)NT * sl / nsl), u1 = (int)((long long)NT * (sl + 1) / nsl);
-    for (int t = u0 + tid; t < u1; t += 256) m = fmaxf(m, Qmax2[(size_t)bh * NT + t]);
-  } else
-  for (int r = r0 + tid; r < r1; r += 256) {
-    float ss = 0.f;
-#pragma unroll
-    for (int c = 0; c < DP; c += 8) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(q + (size_t)r * DP + c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; ss = fmaf(f, f, ss); }
+    for (int rb = rb0 + tid; rb < rb1; rb += 256) {
+      float m = 0.f;
+      const int t1 = min(NT, (rb + 1) * tpr);
+      for (int t = rb * tpr; t < t1; ++t) { const float v = Qmax2[(size_t)bh * NT + t]; m = (v == v) ? fmaxf(m, v) : INFINITY; }
+      blkq[(size_t)bh * nrb + rb] = m;
+      pm = fmaxf(pm, m);
     }
-    m = fmaxf(m, ss);
+  } else {
+    const __bf16* q = Qp + (size_t)bh * NT * 32 * DP;
+    for (int rb = rb0; rb < rb1; ++rb) {
+      const int r1 = min(NT, (rb + 1) * tpr) * 32;
+      float m = 0.f;
+      for (int r = rb * tpr * 32 + tid; r < r1; r += 256) {
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < DP; c += 8) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(q + (size_t)r * DP + c);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; ss = fmaf(f, f, ss); }
+        }
+        m = (ss == ss) ? fmaxf(m, ss) : INFINITY;    // NaN operands: route to the general kernel
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      __syncthreads();
+      if ((tid & 63) == 0) rq[tid >> 6] = m;
+      __syncthreads();
+      m = fmaxf(fmaxf(rq[0], rq[1]), fmaxf(rq[2], rq[3]));
+      if (tid == 0) blkq[(size_t)bh * nrb + rb] = m;
+      pm = fmaxf(pm, m);
+    }
   }
   float km = 0.f;
   const int t0 = (int)((long long)NT * sl / nsl), t1 = (int)((long long)NT * (sl + 1) / nsl);
-  for (int t = t0 + tid; t < t1; t += 256) km = fmaxf(km, Kmax[(size_t)bh * NT + t]);
+  for (int t = t0 + tid; t < t1; t += 256) { const float v = Kmax[(size_t)bh * NT + t]; km = (v == v) ? fmaxf(km, v) : INFINITY; }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { m = fmaxf(m, __shfl_xor(m, off)); km = fmaxf(km, __shfl_xor(km, off)); }
-  if ((tid & 63) == 0) { rq[tid >> 6] = m; rk[tid >> 6] = km; }
+  for (int off = 32; off > 0; off >>= 1) { pm = fmaxf(pm, __shfl_xor(pm, off)); km = fmaxf(km, __shfl_xor(km, off)); }
+  __syncthreads();
+  if ((tid & 63) == 0) { rq[tid >> 6] = pm; rk[tid >> 6] = km; }
   __syncthreads();
   if (tid == 0) {
-    m = fmaxf(fmaxf(rq[0], rq[1]), fmaxf(rq[2], rq[3]));
+    pm = fmaxf(fmaxf(rq[0], rq[1]), fmaxf(rq[2], rq[3]));
     km = fmaxf(fmaxf(rk[0], rk[1]), fmaxf(rk[2], rk[3]));
-    if (!(m == m) || !(km == km)) { m = INFINITY; km = INFINITY; }          // NaN operands: route to the general kernel
-    if (nsl == 1) { bounds[bh].qmax2 = __float_as_uint(m); bounds[bh].kmax = __float_as_uint(km); }
+    if (nsl == 1) { bounds[bh].qmax2 = __float_as_uint(pm); bounds[bh].kmax = __float_as_uint(km); }
     else {
-      atomicMax(&bounds[bh].qmax2, __float_as_uint(m));
+      atomicMax(&bounds[bh].qmax2, __float_as_uint(pm));
       atomicMax(&bounds[bh].kmax, __float_as_uint(km));
     }
   }
@@ -522,7 +559,8 @@ __global__ __launch_bounds__(256) void attn_pair_bounds_k(const __bf16* __restri
 template <int D, int QS, int TS, int SDEN = 0>
 __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict__ Qp, const unsigned char* __restrict__ KVp,
                                                         const PairBounds* __restrict__ bounds, float* __restrict__ out, int ldo,
-                                                        int N, int NT, int heads, int nqb, int npairs, __bf16* __restrict__ out16) {
+                                                        int N, int NT, int heads, int nqb, int npairs, __bf16* __restrict__ out16,
+                                                        const float* __restrict__ blkq, float nm_bound) {
   using G = AttnGeom<D>;
   using SG = StageGeom<D, TS>;
   // head_dim <= 16: the denominator comes out of the ones row of V^T.  head_dim 32 has no spare accumulator row: either an
@@ -545,7 +583,7 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
     bh = wg / nqb;
     qb = wg - bh * nqb;
   }
-  if (!pair_is_bounded(bounds, bh)) return;                // this pair goes through the general kernel
+  if (!block_is_bounded(bounds, blkq, bh, nqb, qb, nm_bound)) return;   // this query block goes through the general kernel
   const int b = bh / heads, head = bh - b * heads;
   const int q0 = qb * (128 * QS) + wave * (32 * QS);
   bf16x8 qf[QS][G::KC];
@@ -580,7 +618,7 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
   const unsigned char* gkv = KVp + (size_t)bh * NT * G::TILE_BYTES;
   const int nstages = (NT + TS - 1) / TS;
   const size_t total_bytes = (size_t)NT * G::TILE_BYTES;
-  const int vrow = G::ONES ? (lr < D ? lr : D) : lr;       // row of the V^T slab this lane reads (row D = ones)
+  const int vrow = vt_row<D, G::ONES>(lr);                 // row of the V^T slab this lane reads (row D = ones)
   const unsigned lds0 = (unsigned)(size_t)lds;
   auto dma = [&](int stage, int buf) {
     const unsigned char* src = gkv + (size_t)stage * SG::STAGE_BYTES;
@@ -680,7 +718,7 @@ __global__ __launch_bounds__(256, 3) void flash_bf16_nm(const __bf16* __restrict
 
 template <int D, int QS, int TS = AttnGeom<D>::TS_DEFAULT, int WPS = 0, int DMA = 1, int DEN = 0, int NMTS = 0, int NMQS = 2, int NMSD = 0>
 void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* ws, hipStream_t s,
-               void* out16) {
+               void* out16, const AttnOpts& opt) {
   using G = AttnGeom<D>;
   using SG = StageGeom<D, TS>;
   const int NT = (N + 31) / 32;
@@ -699,26 +737,37 @@ void run_flash(const float* qkv, float* out, int ldo, int B, int N, int C, int h
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SG::STAGE_BYTES + 2 * TS * 4));
   });
   const PairBounds* skip = nullptr;
+  const float* blkq_c = nullptr;
+  int nrb = 1, rbq = 1;
   if constexpr (NMTS > 0) {
-    // pairs with bounded scores run without a running max (three waves per SIMD); the general kernel takes the rest
+    // query blocks with bounded scores run without a running max (three waves per SIMD); the general kernel takes the rest
     using SN = StageGeom<D, NMTS>;
+    static_assert((128 * NMQS) % (128 * QS) == 0, "a routing block (one no-max workgroup) must be whole general workgroups");
     PairBounds* flags = reinterpret_cast<PairBounds*>(Kmax + (size_t)BH * NT);
-    const float* Qmax2 = qkv ? nullptr : reinterpret_cast<const float*>(flags + BH);   // written by the fused projection (pack targets)
+    float* Qmax2w = reinterpret_cast<float*>(flags + BH);                  // per-tile max |q|^2 (written by the fused projection)
+    float* blkq = Qmax2w + (size_t)BH * NT;                                // per-routing-block max |q|^2
+    const float* Qmax2 = qkv ? nullptr : Qmax2w;
+    constexpr int TPR = 4 * NMQS;                                          // 32-query tiles per routing block
+    const int nqb_nm = (N + 128 * NMQS - 1) / (128 * NMQS);
+    nrb = nqb_nm; rbq = NMQS / QS;
     const int nsl = (!Qmax2 && NT >= 256) ? 32 : 1;
     if (nsl > 1) DDPMIR_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)BH * sizeof(PairBounds), s));
-    hipLaunchKernelGGL(attn_pair_bounds_k<G::DP>, dim3(nsl, BH), dim3(256), 0, s, (const __bf16*)Qp, (const float*)Kmax, NT, flags, Qmax2);
+    hipLaunchKernelGGL(attn_block_bounds_k<G::DP>, dim3(nsl, BH), dim3(256), 0, s, (const __bf16*)Qp, (const float*)Kmax, NT, TPR, nrb, flags,
+                       blkq, Qmax2);
     static PerDeviceOnce attr_nm;
     attr_nm.run([] {
       DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bf16_nm<D, NMQS, NMTS, NMSD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SN::STAGE_BYTES));
     });
-    const int nqb_nm = (N + 128 * NMQS - 1) / (128 * NMQS);
     hipLaunchKernelGGL((flash_bf16_nm<D, NMQS, NMTS, NMSD>), dim3((unsigned)(nqb_nm * BH)), dim3(256), 2 * SN::STAGE_BYTES, s, (const __bf16*)Qp,
-                       (const unsigned char*)KVp, (const PairBounds*)flags, out, ldo, N, NT, heads, nqb_nm, BH, reinterpret_cast<__bf16*>(out16));
+                       (const unsigned char*)KVp, (const PairBounds*)flags, out, ldo, N, NT, heads, nqb_nm, BH, reinterpret_cast<__bf16*>(out16),
+                       (const float*)blkq, opt.nm_bound);
     skip = flags;
+    blkq_c = blkq;
+    if (opt.general_total) *opt.general_total += (int64_t)nqb * BH;
   }
   hipLaunchKernelGGL((flash_bf16<D, QS, TS, WPS, DMA, DEN>), dim3((unsigned)(nqb * BH)), dim3(256), 2 * SG::STAGE_BYTES + 2 * TS * 4, s, Qp, KVp, Kmax,
-                     out, ldo, N, NT, heads, nqb, BH, reinterpret_cast<__bf16*>(out16), skip);
+                     out, ldo, N, NT, heads, nqb, BH, reinterpret_cast<__bf16*>(out16), skip, blkq_c, nrb, rbq, opt.nm_bound, opt.general_taken);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
@@ -726,8 +775,9 @@ template <int D>
 size_t ws_bytes_for(int B, int N, int heads) {
   using G = AttnGeom<D>;
   const size_t NT = (N + 31) / 32, BH = (size_t)B * heads;
+  // ... + per-tile |k| bounds + the pairs' bounds + per-tile max |q|^2 + per-routing-block max |q|^2 (<= one per tile)
   return ((BH * NT * 32 * G::DP * 2 + 255) & ~size_t(255)) + ((BH * NT * G::TILE_BYTES + 255) & ~size_t(255)) +
-         BH * NT * 4 + BH * 8 + BH * NT * 4 + 256;   // ... + per-tile |k| bounds + the pairs' score bounds + per-tile max |q|^2
+         BH * NT * 4 + BH * 8 + BH * NT * 4 + BH * NT * 4 + 256;
 }
 
 }  // namespace
@@ -788,59 +838,60 @@ size_t attention_bf16_workspace(int B, int N, int C, int heads) {
 }
 
 void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* workspace,
-                           hipStream_t s, void* out16) {
+                           hipStream_t s, void* out16, const AttnOpts* opts) {
+  const AttnOpts opt = opts ? *opts : AttnOpts();
   if (!workspace || (!out && !out16)) throw std::logic_error("attention_bf16: workspace / output pointer missing");
 #ifdef DDPMIR_EXPERIMENTS   // tile-shape A/B instantiations (tools/attn_ab*.py); the shipped library has one kernel per head_dim
   const int var = exp_value("DDPMIR_ATTN_VARIANT");
   if (C / heads == 32 && var >= 20) {   // head_dim 32 experiments
     switch (var) {
-      case 20: run_flash<32, 1, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 21: run_flash<32, 1, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 22: run_flash<32, 2, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 23: run_flash<32, 2, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 24: run_flash<32, 1, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 25: run_flash<32, 1, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 26: run_flash<32, 2, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 27: run_flash<32, 1, 8, 3, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 30: run_flash<32, 2, 4, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 50: run_flash<32, 2, 8, 0, 1, 1, 4, 2, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 51: run_flash<32, 2, 8, 0, 1, 1, 4, 2, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 52: run_flash<32, 2, 8, 0, 1, 1, 4, 4, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 53: run_flash<32, 2, 8, 0, 1, 1, 4, 3, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 54: run_flash<32, 2, 8, 0, 1, 1, 8, 2, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 55: run_flash<32, 2, 8, 0, 1, 1, 2, 4, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 56: run_flash<32, 2, 8, 0, 1, 1, 2, 2, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 31: run_flash<32, 2, 16, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 28: run_flash<32, 1, 4, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 29: run_flash<32, 1, 6, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 20: run_flash<32, 1, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 21: run_flash<32, 1, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 22: run_flash<32, 2, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 23: run_flash<32, 2, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 24: run_flash<32, 1, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 25: run_flash<32, 1, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 26: run_flash<32, 2, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 27: run_flash<32, 1, 8, 3, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 30: run_flash<32, 2, 4, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 50: run_flash<32, 2, 8, 0, 1, 1, 4, 2, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 51: run_flash<32, 2, 8, 0, 1, 1, 4, 2, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 52: run_flash<32, 2, 8, 0, 1, 1, 4, 4, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 53: run_flash<32, 2, 8, 0, 1, 1, 4, 3, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 54: run_flash<32, 2, 8, 0, 1, 1, 8, 2, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 55: run_flash<32, 2, 8, 0, 1, 1, 2, 4, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 56: run_flash<32, 2, 8, 0, 1, 1, 2, 2, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 31: run_flash<32, 2, 16, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 28: run_flash<32, 1, 4, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 29: run_flash<32, 1, 6, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
       default: break;
     }
   }
   if (C / heads == 16 && var != 0) {
     switch (var) {
-      case 1: run_flash<16, 1, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 2: run_flash<16, 1, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 3: run_flash<16, 1, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 4: run_flash<16, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 5: run_flash<16, 2, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 6: run_flash<16, 2, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 7: run_flash<16, 2, 16, 0, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 8: run_flash<16, 2, 8, 0, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 9: run_flash<16, 1, 16, 0, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 10: run_flash<16, 2, 8, 3, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 11: run_flash<16, 2, 4, 3, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 14: run_flash<16, 2, 16, 0, 1, 0, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;   // no-max kernel, 2 WG/CU (LDS)
-      case 15: run_flash<16, 2, 16, 0, 1, 0, 12>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;   // 3 WG/CU
-      case 16: run_flash<16, 2, 16, 0, 1, 0, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;    // 4 WG/CU
-      case 17: run_flash<16, 2, 16, 0, 1, 0, 6>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;    // 4 WG/CU, shorter stages
-      case 18: run_flash<16, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;                // the general kernel alone
-      case 19: run_flash<16, 2, 16, 0, 1, 0, 8, 3>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;   // no-max, 3 query sub-tiles per wave
-      case 20: run_flash<16, 2, 16, 0, 1, 0, 12, 3>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 21: run_flash<16, 2, 16, 0, 1, 0, 8, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;   // 4 sub-tiles
-      case 22: run_flash<16, 2, 16, 0, 1, 0, 10, 2>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 23: run_flash<16, 2, 16, 0, 1, 0, 4, 2>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 24: run_flash<16, 2, 16, 0, 1, 0, 12, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
-      case 25: run_flash<16, 2, 16, 0, 1, 0, 6, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); return;
+      case 1: run_flash<16, 1, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 2: run_flash<16, 1, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 3: run_flash<16, 1, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 4: run_flash<16, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 5: run_flash<16, 2, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 6: run_flash<16, 2, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 7: run_flash<16, 2, 16, 0, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 8: run_flash<16, 2, 8, 0, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 9: run_flash<16, 1, 16, 0, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 10: run_flash<16, 2, 8, 3, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 11: run_flash<16, 2, 4, 3, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 14: run_flash<16, 2, 16, 0, 1, 0, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;   // no-max kernel, 2 WG/CU (LDS)
+      case 15: run_flash<16, 2, 16, 0, 1, 0, 12>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;   // 3 WG/CU
+      case 16: run_flash<16, 2, 16, 0, 1, 0, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;    // 4 WG/CU
+      case 17: run_flash<16, 2, 16, 0, 1, 0, 6>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;    // 4 WG/CU, shorter stages
+      case 18: run_flash<16, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;                // the general kernel alone
+      case 19: run_flash<16, 2, 16, 0, 1, 0, 8, 3>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;   // no-max, 3 query sub-tiles per wave
+      case 20: run_flash<16, 2, 16, 0, 1, 0, 12, 3>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 21: run_flash<16, 2, 16, 0, 1, 0, 8, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;   // 4 sub-tiles
+      case 22: run_flash<16, 2, 16, 0, 1, 0, 10, 2>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 23: run_flash<16, 2, 16, 0, 1, 0, 4, 2>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 24: run_flash<16, 2, 16, 0, 1, 0, 12, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
+      case 25: run_flash<16, 2, 16, 0, 1, 0, 6, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
       default: break;
     }
   }
@@ -851,18 +902,18 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
     // ... and 16-tile (512-key) stages: one barrier per 32 K scores per wave (A/B: TS 4/8/16 = 8.86/7.66/7.24 ms)
     // ... bounded scores (the normal case) take the no-max kernel: four query sub-tiles per wave at three waves per SIMD
     // (A/B on one device, B=4, N=65 536: general kernel 7.30 ms; no-max QS/TS 2/12 6.96, 2/8 6.97, 3/8 7.09, 4/8 6.84)
-    case 8: run_flash<8, 2, 16, 0, 1, 0, 8, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
-    case 16: run_flash<16, 2, 16, 0, 1, 0, 8, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
+    case 8: run_flash<8, 2, 16, 0, 1, 0, 8, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); break;
+    case 16: run_flash<16, 2, 16, 0, 1, 0, 8, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); break;
     case 32:   // bounded scores: no-max kernel at 3 waves/SIMD (16 KiB stages, scalar-add denominators); general kernel otherwise
-      if ((N % 32) == 0) run_flash<32, 2, 8, 0, 1, 1, 4, 2, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16);
-      else run_flash<32, 2, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16);
+      if ((N % 32) == 0) run_flash<32, 2, 8, 0, 1, 1, 4, 2, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt);
+      else run_flash<32, 2, 8, 0, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt);
       break;
     case 64:   // bounded scores: no-max kernel (one query sub-tile per wave, 16 KiB stages, scalar-add denominators): 355 -> 269 us
       // at N = 4096, B = 16; below N = 2048 its bounds pass and memset cost more than it saves
-      if ((N % 32) == 0 && N >= 2048) run_flash<64, 1, AttnGeom<64>::TS_DEFAULT, 0, 1, 0, 2, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16);
-      else run_flash<64, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16);
+      if ((N % 32) == 0 && N >= 2048) run_flash<64, 1, AttnGeom<64>::TS_DEFAULT, 0, 1, 0, 2, 1, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt);
+      else run_flash<64, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt);
       break;
-    case 128: run_flash<128, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16); break;
+    case 128: run_flash<128, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); break;
     default: throw std::runtime_error("attention_bf16: unsupported head dim");
   }
 }

@@ -783,7 +783,10 @@ bool gemm16_can_fuse_gn(const IGemm& p, int groups) {
 
 bool gemm16_supported(const IGemm& p) {
   const int al = p.f8 ? 16 : 8;       // a 16-byte chunk holds 16 e4m3 or 8 bf16 K elements
-  return p.A16 && p.Wt16 && p.zero16 && (p.Cin % al) == 0 && (p.lda16 % al) == 0 && (p.Cout % 4) == 0 &&
+  // (an output is required: a launch with every output pointer NULL would run its epilogue into address 0)
+  return p.A16 && p.Wt16 && p.zero16 && (p.out || p.out16 || p.out8 || p.pk_q) && (!p.out || p.ldo >= (p.sel_C ? p.sel_C : p.Cout)) &&
+         (!p.out16 || p.ldo16 > 0) && (!p.out8 || p.ldo8 > 0) && (!p.res || p.ldres > 0) && (!p.mul || p.ldmul > 0) && (!p.tb || p.ldtb > 0) &&
+         (p.Cin % al) == 0 && (p.lda16 % al) == 0 && (p.Cout % 4) == 0 &&
          p.store == STORE_NHWC && p.pro_mask == MASK_NONE && !p.scale && p.pro_act == ACT_NONE && !(p.f8 && (p.Cinb || p.pk_q));
 }
 

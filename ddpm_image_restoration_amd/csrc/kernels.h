@@ -100,10 +100,20 @@ struct AttnPack16 { void* q; void* kv; float* kmax; int ntiles; float qscale; in
 bool attention_bf16_prepack_supported(int N, int C, int heads);
 AttnPack16 attention_bf16_pack_targets(int B, int N, int C, int heads, void* workspace);
 size_t attention_bf16_workspace(int B, int N, int C, int heads);
+// Routing between the no-max kernel and the general (running-max) kernel, per (batch, head, block of 128..512 queries):
+// a block runs without a running max when  max|q| of its queries * max|k| of its pair <= nm_bound  (log2 units; 80 keeps
+// 2^s, the sums over 2^18 keys and the PV accumulators inside fp32).  nm_bound < 0 sends everything to the general kernel.
+// general_taken (device) / general_total (host): profiling counters -- general-kernel workgroups that did the work /
+// general-kernel workgroups launched beside a no-max kernel.
+struct AttnOpts {
+  float nm_bound = 80.0f;
+  unsigned* general_taken = nullptr;
+  int64_t* general_total = nullptr;
+};
 // out16 != nullptr: the result is written as bf16 [B][N][C] there instead of fp32 `out`
 // qkv == nullptr: the operand images in `workspace` were already written by the producer (AttnPack16)
 void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, int C, int heads, void* workspace,
-                           hipStream_t stream, void* out16 = nullptr);
+                           hipStream_t stream, void* out16 = nullptr, const AttnOpts* opts = nullptr);
 
 // ------------------------------------------------------------------------------------------------ pointwise
 // GroupNorm statistics -> per-(b,c) scale/shift so that norm(x) = x*scale + shift (eps 1e-5, biased var).

@@ -111,6 +111,7 @@ class Context {
   void jpeg_roundtrip(const uint8_t* in, uint8_t* out, int B, int H, int W, int quality);
   void profile_enable(int enable);
   void profile_read(const std::string& cls, double* ms, int64_t* launches, double* flops);
+  void set_option(const std::string& name, double value);
 
  private:
   // ---- weights
@@ -125,6 +126,7 @@ class Context {
   bool finalized_ = false;
   int64_t n_params_ = 0;
   int nt_total_ = 0;
+  size_t blob_bytes_ = 0;          // packed blob size, measured once (weight_blob_bytes)
   void layout_weights(Arena& a, bool upload);
   void put(Arena& a, bool upload, float*& dst, const std::string& name, size_t expect);
   void put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name, int cout, int cin, int ksz);
@@ -202,8 +204,15 @@ class Context {
   std::vector<ProfSpan> prof_spans_;
   std::vector<hipEvent_t> prof_pool_;
   bool prof_on_ = false, prof_open_ = false;
-  int prof_detail_ = 0;             // 1 = forward + full-resolution attention spans, 2 = every attention launch
-  double prof_ms_[3] = {0, 0, 0}; int64_t prof_n_[3] = {0, 0, 0}; double prof_flops_[3] = {0, 0, 0};
+  int prof_detail_ = 0;             // 1 = forward + full-resolution attention spans, 2 = every attention launch, 3 = + every GEMM launch
+  static constexpr int kProfClasses = 5;
+  double prof_ms_[kProfClasses] = {}; int64_t prof_n_[kProfClasses] = {}; double prof_flops_[kProfClasses] = {};
+  // attention routing (attention_bf16.hip): score bound of the no-max kernel, and -- while profiling -- how many workgroups of
+  // the general (running-max) kernel had work to do out of those launched beside a no-max kernel
+  float attn_nm_bound_ = 80.0f;
+  unsigned* attn_general_taken_ = nullptr;   // device counter
+  int64_t attn_general_total_ = 0;
+  AttnOpts attn_opts();
   hipEvent_t prof_event();
   void prof_begin(int cls, double flops, hipStream_t s);
   void prof_end(hipStream_t s);

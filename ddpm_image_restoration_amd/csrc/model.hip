@@ -37,6 +37,21 @@ ArchConsts consts_for(int arch) {
   }
 }
 
+// DDPMIR_DEBUG_SYNC=1 (diagnostics, read once): synchronise after every stage of a forward and name it on stderr, so that a
+// GPU memory-access fault -- reported asynchronously, without a kernel name -- is pinned to the stage that was running.
+bool debug_sync_enabled() {
+  static const bool on = [] { const char* e = getenv("DDPMIR_DEBUG_SYNC"); return e && *e && *e != '0'; }();
+  return on;
+}
+void debug_stage(hipStream_t s, const char* block, const char* what, int B, int H, int W, int C) {
+  if (!debug_sync_enabled()) return;
+  fprintf(stderr, "[ddpmir] %s %s B=%d %dx%d C=%d ...", block, what, B, H, W, C);
+  fflush(stderr);
+  const hipError_t e = hipStreamSynchronize(s);
+  fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+  fflush(stderr);
+}
+
 }  // namespace
 
 Context::Context(const ddpmir_config& c) : cfg(c), k(consts_for(c.arch)) {
@@ -48,12 +63,15 @@ Context::Context(const ddpmir_config& c) : cfg(c), k(consts_for(c.arch)) {
   DDPMIR_HIP_CHECK(hipEventCreate(&ev1_));
   DDPMIR_HIP_CHECK(hipEventCreateWithFlags(&lane_ev_[0], hipEventDisableTiming));
   DDPMIR_HIP_CHECK(hipEventCreateWithFlags(&lane_ev_[1], hipEventDisableTiming));
+  DDPMIR_HIP_CHECK(hipMalloc(&attn_general_taken_, 16));
+  DDPMIR_HIP_CHECK(hipMemset(attn_general_taken_, 0, 16));
 }
 
 Context::~Context() {
   (void)hipSetDevice(cfg.device);
   free_plan();
   if (wblob_ && wblob_owned_) (void)hipFree(wblob_);
+  if (attn_general_taken_) (void)hipFree(attn_general_taken_);
   if (pin_in_) (void)hipHostFree(pin_in_);
   if (pin_out_) (void)hipHostFree(pin_out_);
   for (auto& sp : prof_spans_) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
@@ -286,9 +304,18 @@ void Context::layout_weights(Arena& a, bool up) {
 }
 
 size_t Context::weight_blob_bytes() {
-  Arena a;
-  layout_weights(a, false);
-  return (a.off + 255) & ~size_t(255);
+  // The size comes from a DRY RUN of layout_weights (no base address), which re-points every weight pointer of the context
+  // at offsets from NULL.  That is harmless before finalize_weights (which lays them out again over the real blob) and was
+  // a latent fault after it: a later forward read its weights from addresses like 0x31000 ("Memory access fault by GPU ...
+  // on address 0x31000", round 3; bench.py asked for the blob size between two sampling calls).  The layout only depends on
+  // the configuration, so it is measured once and cached; after finalize the pointers are never touched again.
+  if (blob_bytes_ == 0) {
+    if (finalized_) throw std::logic_error("weight_blob_bytes: layout was not measured before finalize_weights");
+    Arena a;
+    layout_weights(a, false);
+    blob_bytes_ = (a.off + 255) & ~size_t(255);
+  }
+  return blob_bytes_;
 }
 
 void Context::finalize_weights(void* dev_blob, int fill) {
@@ -451,7 +478,7 @@ void Context::ensure_plan(int B, int H, int W) {
 }
 
 // ------------------------------------------------------------------------------------------------ profiling
-enum { PROF_ATTN_L0 = 0, PROF_ATTN = 1, PROF_FWD = 2 };
+enum { PROF_ATTN_L0 = 0, PROF_ATTN = 1, PROF_FWD = 2, PROF_GEMM = 3, PROF_GEMM8 = 4 };
 
 hipEvent_t Context::prof_event() {
   if (!prof_pool_.empty()) { hipEvent_t e = prof_pool_.back(); prof_pool_.pop_back(); return e; }
@@ -463,7 +490,7 @@ void Context::prof_begin(int cls, double flops, hipStream_t s) {
   prof_open_ = false;
   // the coarse level (1) brackets the forward and its two full-resolution attention launches only -- 6 event records per
   // forward instead of 54 -- so that the measured stream carries as few markers as the roofline figures need
-  if (!prof_on_ || (cls == PROF_ATTN && prof_detail_ < 2)) return;
+  if (!prof_on_ || (cls == PROF_ATTN && prof_detail_ < 2) || ((cls == PROF_GEMM || cls == PROF_GEMM8) && prof_detail_ < 3)) return;
   ProfSpan sp{prof_event(), prof_event(), cls, flops};
   DDPMIR_HIP_CHECK(hipEventRecord(sp.a, s));
   prof_spans_.push_back(sp);
@@ -490,8 +517,11 @@ void Context::profile_enable(int enable) {
   if (enable) {
     // (with use_graph = 1 the loop and predict() launch eagerly while profiling is on: events cannot bracket graph nodes)
     prof_collect();
-    for (int i = 0; i < 3; ++i) { prof_ms_[i] = 0; prof_n_[i] = 0; prof_flops_[i] = 0; }
+    for (int i = 0; i < kProfClasses; ++i) { prof_ms_[i] = 0; prof_n_[i] = 0; prof_flops_[i] = 0; }
     codec_host_ms_ = 0.0; codec_calls_ = 0;
+    DDPMIR_HIP_CHECK(hipStreamSynchronize(stream_));
+    DDPMIR_HIP_CHECK(hipMemset(attn_general_taken_, 0, 16));
+    attn_general_total_ = 0;
   }
   prof_on_ = enable != 0;
   prof_detail_ = enable;
@@ -504,11 +534,40 @@ void Context::profile_read(const std::string& cls, double* ms, int64_t* launches
     if (flops) *flops = 0.0;
     return;
   }
-  int c = cls == "attention_l0" ? PROF_ATTN_L0 : cls == "attention" ? PROF_ATTN : cls == "forward" ? PROF_FWD : -1;
+  if (cls == "attention_general") {   // launches = general-kernel workgroups that had work, flops = those launched beside a no-max kernel
+    unsigned taken = 0;
+    DDPMIR_HIP_CHECK(hipStreamSynchronize(stream_));
+    DDPMIR_HIP_CHECK(hipMemcpy(&taken, attn_general_taken_, 4, hipMemcpyDeviceToHost));
+    if (ms) *ms = 0.0;
+    if (launches) *launches = (int64_t)taken;
+    if (flops) *flops = (double)attn_general_total_;
+    return;
+  }
+  int c = cls == "attention_l0" ? PROF_ATTN_L0 : cls == "attention" ? PROF_ATTN : cls == "forward" ? PROF_FWD :
+          cls == "gemm" ? PROF_GEMM : cls == "gemm_fp8" ? PROF_GEMM8 : -1;
   if (c < 0) throw std::invalid_argument("unknown profile class " + cls);
   if (ms) *ms = prof_ms_[c];
   if (launches) *launches = prof_n_[c];
   if (flops) *flops = prof_flops_[c];
+}
+
+AttnOpts Context::attn_opts() {
+  AttnOpts o;
+  o.nm_bound = attn_nm_bound_;
+  if (prof_on_) { o.general_taken = attn_general_taken_; o.general_total = &attn_general_total_; }
+  return o;
+}
+
+void Context::set_option(const std::string& name, double value) {
+  if (name == "attention_no_max_bound") {   // log2 units; < 0: every query block takes the general (running-max) kernel
+    if (!(value <= 80.0)) throw std::invalid_argument("attention_no_max_bound must be <= 80 (fp32 range of 2^s sums)");
+    attn_nm_bound_ = (float)value;
+    drop_loop_graphs();                     // captured timesteps bake the bound in
+    if (plan_.gexec) { (void)hipGraphExecDestroy(plan_.gexec); plan_.gexec = nullptr; }
+    if (plan_.graph) { (void)hipGraphDestroy(plan_.graph); plan_.graph = nullptr; }
+    return;
+  }
+  throw std::invalid_argument("unknown option " + name);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -623,16 +682,22 @@ void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
 void Context::conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override) {
   p.Wt = nullptr; p.Wt16 = cw.w16; p.bias = bias_override ? bias_override : cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
   p.zero16 = plan_.zero16; p.splitk_ws = plan_.splitk_ws; p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
-  if (gemm16_supported(p)) launch_gemm16(p, s);
-  else throw std::logic_error("conv16: operand layout not supported by the DMA GEMM");
+  if (!gemm16_supported(p)) throw std::logic_error("conv16: operand layout not supported by the DMA GEMM");
+  // algorithmic FLOPs: 2 M N K over the real channel counts (a stacked gate pair counts its two layers, not the zero blocks)
+  const double M = (double)p.B * p.H * p.W;
+  prof_begin(PROF_GEMM, 2.0 * M * (p.sel_C ? 0.5 : 1.0) * ((double)cw.cout * cw.cin * cw.taps + (p.Cinb ? (double)cw.cout * p.Cinb : 0.0)), s);
+  launch_gemm16(p, s);
+  prof_end(s);
 }
 
 void Context::conv8(const ConvW& cw, IGemm p, hipStream_t s) {
   p.Wt = nullptr; p.Wt16 = cw.w8; p.bias = cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
   p.f8 = 1; p.acc_scale = cw.w8_inv;
   p.zero16 = plan_.zero16; p.splitk_ws = plan_.splitk_ws; p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
-  if (gemm16_supported(p)) launch_gemm16(p, s);
-  else throw std::logic_error("conv8: operand layout not supported by the fp8 GEMM");
+  if (!gemm16_supported(p)) throw std::logic_error("conv8: operand layout not supported by the fp8 GEMM");
+  prof_begin(PROF_GEMM8, 2.0 * (double)p.B * p.H * p.W * (double)cw.cout * cw.cin * cw.taps, s);
+  launch_gemm16(p, s);
+  prof_end(s);
 }
 
 // bf16 mode, DCT families: every GEMM input is a bf16 tensor written once by its producer (GroupNorm-apply pass,
@@ -643,9 +708,11 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   Plan& p = plan_;
   const int B = fb_, C = bw.cout, HW = H * W;
   const int cin8 = round_up(bw.cin, 8);
+#define STAGE(what) debug_stage(s, bw.name.c_str(), what, B, H, W, C)
   IGemm g; g.B = B; g.H = H; g.W = W; g.bs = k.dct_block; g.low = k.low_size;
   // norm1 -> conv1 (+ bias + time projection)
   launch_gn_scale_shift(in, ldin, B, HW, bw.cin, gn_groups(bw.cin), bw.n1g, bw.n1b, p.gn_partial, p.sc1, p.sh1, s);
+  STAGE("norm1 statistics");
   // (3-channel image input: x4 carries a zero 4th channel, gn_finalize zeroes its scale/shift, a16 pads to 8)
   IGemm c1 = g; c1.A16 = p.a16; c1.lda16 = cin8; c1.tb = p.tproj + bw.tproj_off; c1.ldtb = nt_total_;
   c1.out = p.hA; c1.ldo = C;
@@ -658,14 +725,18 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   const bool c1_f8 = bw.conv1.w8 != nullptr, c2_f8 = bw.conv2.w8 != nullptr, co_f8 = bw.conv_out.w8 != nullptr;
   launch_gn_apply16(in, ldin, B, HW, bw.cinp, p.sc1, p.sh1, ACT_NONE, c1_f8 ? nullptr : p.a16, cin8, bw.has_shortcut ? p.x16 : nullptr,
                     cin8, s, fuse_gn ? p.gn_sums : nullptr, fuse_gn ? B * GN_SUM_SLOTS * gn_groups(C) * 2 : 0, c1_f8 ? p.a8 : nullptr, bw.conv1.cin16);
+  STAGE("norm1 apply");
   if (fuse_gn) { c1.gn_sums = p.gn_sums; c1.gn_groups = gn_groups(C); }
   if (c1_f8) { c1.A16 = p.a8; c1.lda16 = bw.conv1.cin16; conv8(bw.conv1, c1, s); }
   else conv16(bw.conv1, c1, s);
+  STAGE("conv1");
   // norm2 -> GELU -> conv2 ; hB also as bf16 for the qkv projection
   if (fuse_gn) launch_gn_from_sums(p.gn_sums, B, HW, C, gn_groups(C), bw.n2g, bw.n2b, p.sc2, p.sh2, s);
   else launch_gn_scale_shift(p.hA, C, B, HW, C, gn_groups(C), bw.n2g, bw.n2b, p.gn_partial, p.sc2, p.sh2, s);
+  STAGE("norm2 statistics");
   launch_gn_apply16(p.hA, C, B, HW, C, p.sc2, p.sh2, ACT_GELU, c2_f8 ? nullptr : p.a16, C, nullptr, 0, s, nullptr, 0,
                     c2_f8 ? p.a8 : nullptr, C);
+  STAGE("norm2 apply + GELU");
   const bool attn = bw.level >= cfg.attn_min_level;
   // 64- and 128-channel blocks of the DCT families: DCT, both gate layers and S = x + g * xd run as one pass over x
   const bool fuse_freq = cfg.arch != DDPMIR_ARCH_AVIF && !exp_switch("DDPMIR_SPLIT_GATES") && !co_f8 && !exp_switch("DDPMIR_NO_FREQ_FUSE") &&
@@ -674,6 +745,7 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   if (attn) { c2.out16 = p.hB16; c2.ldo16 = C; }
   if (c2_f8) { c2.A16 = p.a8; conv8(bw.conv2, c2, s); }
   else conv16(bw.conv2, c2, s);
+  STAGE("conv2");
   if (attn) {
     // head_dim 16 levels: the projection's epilogue writes the attention operand images itself (no fp32 qkv round trip)
     const bool no_fuse = exp_switch("DDPMIR_NO_QKV_FUSE");
@@ -686,21 +758,25 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
       q.out = p.qkv; q.ldo = 3 * C;
     }
     conv16(bw.in_proj, q, s);
+  STAGE("attention in_proj");
     const double nn = (double)HW;
     prof_begin(bw.level == 0 ? PROF_ATTN_L0 : PROF_ATTN, 4.0 * nn * nn * C * B, s);
     if (attention_bf16_supported(HW, C, k.heads)) {
-      launch_attention_bf16(prepack ? nullptr : p.qkv, p.att, C, B, HW, C, k.heads, p.attn_ws, s, p.att16);
+      const AttnOpts ao = attn_opts();
+      launch_attention_bf16(prepack ? nullptr : p.qkv, p.att, C, B, HW, C, k.heads, p.attn_ws, s, p.att16, &ao);
     } else {
       launch_attention(p.qkv, p.att, C, B, HW, C, k.heads, s);
       launch_gn_apply16(p.att, C, B, HW, C, nullptr, nullptr, ACT_NONE, p.att16, C, nullptr, 0, s);
     }
     prof_end(s);
+    STAGE("attention core");
     // 64-channel blocks: the output projection and its residual are formed inside the frequency-block kernel (level 0:
     // 135 + 165 us -> 231 us); at 128 channels the extra GEMM on 64-pixel tiles costs more than the pass it saves (176 vs 150 us)
     if (!(fuse_freq && C == 64)) {
       IGemm o = g; o.A16 = p.att16; o.lda16 = C; o.res = p.hB; o.ldres = C; o.out = p.hB; o.ldo = C;
       if (cfg.arch == DDPMIR_ARCH_AVIF) { o.out16 = p.hB16; o.ldo16 = C; }   // the colour / edge gates read x as bf16
       conv16(bw.out_proj, o, s);
+      STAGE("attention out_proj");
     }
   } else if (cfg.arch == DDPMIR_ARCH_AVIF) {
     launch_gn_apply16(p.hB, C, B, HW, C, nullptr, nullptr, ACT_NONE, p.hB16, C, nullptr, 0, s);
@@ -736,6 +812,7 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
     if (co_f8) { d.out8 = p.S8; d.ldo8 = C; } else { d.out16 = p.S16; d.ldo16 = C; }
     conv16(bw.high2, d, s);
   }
+  STAGE("frequency block");
   // conv_out + residual; a 1x1 shortcut conv rides along as a second K segment of the same GEMM (identity shortcuts
   // are the plain fp32 residual)
   IGemm co = g; co.A16 = p.S16; co.lda16 = C; co.out = dest; co.ldo = lddest;
@@ -764,6 +841,8 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
     }
     conv16(bw.conv_out, co, s);
   }
+  STAGE("conv_out (+ shortcut)");
+#undef STAGE
 }
 
 void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest,
@@ -845,6 +924,7 @@ void Context::fwd_head(const float* x, const float* t, const float* cl, int row0
   if (!whole && prof_on_ && !prof_spans_.empty()) prof_spans_.back().count = 0;   // a piece: its time counts, not its number
   float* x4 = p.x4 + (size_t)row0 * HW * 4;
   launch_nchw3_to_nhwc4(x, x4, nb, H, W, s);
+  debug_stage(s, "forward", "image layout NCHW3 -> NHWC4", nb, H, W, 3);
   launch_time_embed(t, nb, tw_, p.hidden + (size_t)row0 * 1024, p.temb + (size_t)row0 * 256, p.tproj + (size_t)row0 * nt_total_, s);
   if (cfg.arch == DDPMIR_ARCH_AVIF) {
     launch_cl_boost(cl, nb, 0.5f, 0.5f, 0.3f, 1.5f, p.boost + row0, s);    // colour   avif_inference.py:246
@@ -855,6 +935,7 @@ void Context::fwd_head(const float* x, const float* t, const float* cl, int row0
   {
     SideRows rows(p.tproj, p.boost, p.boost2, p.constmix, row0, nt_total_);
     // the skip tensor goes straight into the second half of up5's concat buffer
+    debug_stage(s, "forward", "image layout + time embedding", nb, H, W, 3);
     run_block(blocks_[0], x4, 4, H, W, p.cat[0] + (size_t)row0 * HW * 128 + 64, 128, s);
   }
   if (!whole) prof_close_forward(s);
@@ -878,6 +959,7 @@ void Context::fwd_mid(int B, bool whole, hipStream_t s) {
     float* d = p.cat[l] + skip_off[l];
     run_block(blocks_[l], in, ldin, hh(l), ww(l), d, cat_c[l], s);
     launch_maxpool2(d, cat_c[l], p.pin[l + 1], skip_c[l], B, hh(l), ww(l), skip_c[l], s);
+    debug_stage(s, "forward", "max-pool", B, hh(l), ww(l), skip_c[l]);
     in = p.pin[l + 1]; ldin = skip_c[l];
   }
   run_block(blocks_[5], p.pin[5], 512, hh(5), ww(5), p.bb0, 1024, s);
@@ -887,6 +969,7 @@ void Context::fwd_mid(int B, bool whole, hipStream_t s) {
   const float* prev = p.bb2; int prev_c = 512;
   for (int l = 4; l >= 1; --l) {
     launch_upsample2(prev, prev_c, p.cat[l], cat_c[l], B, hh(l + 1), ww(l + 1), prev_c, s);
+    debug_stage(s, "forward", "bilinear x2", B, hh(l + 1), ww(l + 1), prev_c);
     const BlockW& bw = blocks_[8 + (4 - l)];
     run_block(bw, p.cat[l], cat_c[l], hh(l), ww(l), p.u[l], bw.cout, s);
     prev = p.u[l]; prev_c = bw.cout;
@@ -924,6 +1007,7 @@ void Context::fwd_tail(float* out, int row0, int nb, bool whole, hipStream_t s) 
     hc.pro_act = ACT_SILU; hc.epi_act = ACT_TANH; hc.out = out; hc.ldo = 0; hc.store = STORE_NCHW;
     conv(head_conv_, hc, s);
   }
+  debug_stage(s, "forward", "head (transform mix, GroupNorm, SiLU, conv 64->3, tanh)", nb, H, W, 64);
   prof_close_forward(s);
 }
 
@@ -942,6 +1026,12 @@ void Context::predict(const float* x, const float* t, const float* cl, float* ou
   fb_ = B;
   const bool own = (s == nullptr);
   hipStream_t st = own ? stream_ : s;
+  if (own) {
+    // the caller's inputs were produced on ITS stream -- the default stream when NULL was passed -- and the context's stream
+    // is non-blocking (no implicit ordering against the default stream): order it explicitly
+    DDPMIR_HIP_CHECK(hipEventRecord(lane_ev_[0], nullptr));
+    DDPMIR_HIP_CHECK(hipStreamWaitEvent(st, lane_ev_[0], 0));
+  }
   Plan& p = plan_;
   const size_t n_img = (size_t)B * 3 * H * W;
   if (cfg.use_graph && !prof_on_) {
@@ -1091,6 +1181,7 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
   const bool do_phase = quality < phase_q;
   DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_y, y, n * 4, hipMemcpyDeviceToDevice, s));     // y = x_t.clone()
   DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_xt, y, n * 4, hipMemcpyDeviceToDevice, s));
+  debug_stage(s, "loop", "copy y", B, H, W, 3);
   const int i_first = (opts->start_step >= 0 && opts->start_step < steps) ? opts->start_step : steps - 1;
   const int i_last = opts->num_steps > 0 ? std::max(0, i_first - opts->num_steps + 1) : 0;
 
@@ -1103,9 +1194,11 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
   const size_t nh = (size_t)nb * 3 * H * W;                 // elements per lane
   if (do_phase)
     for (int l = 0; l < nl; ++l) phase_prepare(p.s_y + l * nh, nb, H, W, s, l * nh);
+  debug_stage(s, "loop", "reference phase of y (fp64 DFT)", B, H, W, 3);
   for (int l = 0; l < nl; ++l)
     launch_step_params_set(p.sp + l, i_first, steps, coeff, opts->seed,
                            (opts->image_offset + (uint64_t)l * nb) * (uint64_t)(3 * H * W) / 4, opts->noise, (int64_t)n, s);
+  debug_stage(s, "loop", "step parameters", B, H, W, 3);
 
   // captured timesteps are valid for one set of baked-in scalars; anything else (seed, noise, offsets, i) is in plan_.sp
   const bool graphs = cfg.use_graph && !prof_on_;   // HIP-event spans cannot bracket nodes of a replayed graph

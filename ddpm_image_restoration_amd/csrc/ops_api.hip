@@ -382,6 +382,25 @@ int ddpmir_op_attention_bf16(const float* qkv, int B, int N, int C, int heads, f
   });
 }
 
+int ddpmir_op_attention_bf16_ex(const float* qkv, int B, int N, int C, int heads, float nm_bound, float* out, int64_t* stats) {
+  return guarded([&] {
+    if (!attention_bf16_supported(N, C, heads)) throw std::runtime_error("attention_bf16: unsupported shape");
+    Dev d;
+    float* q = d.up(qkv, (size_t)B * N * 3 * C);
+    float* o = d.alloc<float>((size_t)B * N * C);
+    unsigned char* ws = d.alloc<unsigned char>(attention_bf16_workspace(B, N, C, heads) + 256);
+    unsigned* taken = d.alloc<unsigned>(4);
+    int64_t total = 0;
+    AttnOpts ao;
+    ao.nm_bound = nm_bound; ao.general_taken = taken; ao.general_total = &total;
+    launch_attention_bf16(q, o, C, B, N, C, heads, ws, nullptr, nullptr, &ao);
+    d.down(out, o, (size_t)B * N * C);
+    unsigned t = 0;
+    d.down(&t, taken, 1);
+    if (stats) { stats[0] = (int64_t)t; stats[1] = total; }
+  });
+}
+
 int ddpmir_op_attention_time(int B, int N, int C, int heads, int mode, int iters, float* ms_per_call) {
   return guarded([&] {
     Dev d;

@@ -173,9 +173,18 @@ class _RestorationModel:
     def weight_blob_bytes(self) -> int:
         return int(self._lib.ddpmir_weight_blob_bytes(self._ctx))
 
-    def profile(self, enable, detail: bool = False):
-        """HIP-event spans: forwards + full-resolution attention launches; detail=True brackets all 13 attention launches."""
-        _lib.check(self._lib, self._ctx, self._lib.ddpmir_profile_enable(self._ctx, (2 if detail else 1) if enable else 0), "profile_enable")
+    def profile(self, enable, detail=False):
+        """HIP-event spans: forwards + full-resolution attention launches; detail=True (or 2) brackets all 13 attention
+        launches, detail=3 also every GEMM launch (classes "gemm" / "gemm_fp8")."""
+        level = 0 if not enable else (int(detail) if int(detail) > 1 else (2 if detail else 1))
+        _lib.check(self._lib, self._ctx, self._lib.ddpmir_profile_enable(self._ctx, level), "profile_enable")
+
+    def set_option(self, name: str, value: float):
+        """ddpmir_set_option: e.g. ("attention_no_max_bound", -1.0) forces the general attention kernel."""
+        _lib.check(self._lib, self._ctx, self._lib.ddpmir_set_option(self._ctx, name.encode(), float(value)), f"set_option({name})")
+
+    def version(self) -> str:
+        return self._lib.ddpmir_version().decode()
 
     def profile_read(self, cls: str):
         """(device ms, launches, algorithmic FLOPs) accumulated for a kernel class since profile(True)."""

@@ -19,6 +19,7 @@ _sigs = {
     "ddpmir_op_gn_scale_shift": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "ddpmir_op_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ddpmir_op_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ddpmir_op_attention_bf16_ex": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
     "ddpmir_op_conv_gnstats_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "ddpmir_op_conv_dual_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P]),
     "ddpmir_op_qkv_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
@@ -117,6 +118,17 @@ def attention(qkv, heads, bf16=False):
     fn = lib.ddpmir_op_attention_bf16 if bf16 else lib.ddpmir_op_attention
     _chk(lib, fn(_p(qkv), b, n, c3 // 3, heads, _p(out)), "op_attention")
     return out
+
+
+def attention_bf16_routed(qkv, heads, nm_bound=80.0):
+    """bf16 attention with an explicit routing bound; returns (out, general workgroups with work, general workgroups launched)."""
+    lib = _lib_ops()
+    qkv = _f(qkv)
+    b, n, c3 = qkv.shape
+    out = np.empty((b, n, c3 // 3), np.float32)
+    stats = np.zeros(2, np.int64)
+    _chk(lib, lib.ddpmir_op_attention_bf16_ex(_p(qkv), b, n, c3 // 3, heads, float(nm_bound), _p(out), stats.ctypes.data_as(_P)), "op_attention_ex")
+    return out, int(stats[0]), int(stats[1])
 
 
 def conv_gnstats_bf16(x, w, bias, groups):

@@ -137,9 +137,21 @@ int ddpmir_jpeg_roundtrip_u8(ddpmir_ctx* ctx, const uint8_t* in_u8_nchw, uint8_t
  * "codec_host" (HOST milliseconds spent inside the codec callback / built-in pool of the sampling loop, and the number of
  * calls).  enable = 1 brackets the forwards and the full-resolution attention launches only (6 event records per
  * forward); enable = 2 every attention launch (54 records per forward); 0 stops. */
+/* enable = 3 additionally brackets every GEMM launch (conv3x3 / 1x1 / projections of the DMA-streamed bf16 / fp8 path): classes
+ * "gemm" and "gemm_fp8" with algorithmic FLOPs 2*M*N*K -- about 220 event records per forward, so not for timed regions.
+ * "attention_general": launches = workgroups of the general (running-max) attention kernel that had work to do, flops = such
+ * workgroups launched beside a no-max kernel (the share of query blocks whose score bound forced the running max). */
 int ddpmir_profile_enable(ddpmir_ctx* ctx, int enable);
 int ddpmir_profile_read(ddpmir_ctx* ctx, const char* cls, double* ms, int64_t* launches, double* flops);
+/* "ddpmir <semver> (gfx950) src=<sha256/16 of csrc + include> hipcc=<version the library was built with>": lets a caller
+ * (bench.py prints it) tell a stale prebuilt binary from a fresh compile of the sources beside it. */
 const char* ddpmir_version(void);
+
+/* Tuning / diagnostic options of a context.  "attention_no_max_bound" (default 80, log2 units): a block of queries runs in
+ * the attention kernel WITHOUT a running softmax maximum when max|q| of the block * max|k| of its (batch, head) pair stays
+ * below it (scores then cannot leave fp32's range); a negative value forces the general kernel everywhere (the worst case
+ * bench.py reports as general_kernel_only). */
+int ddpmir_set_option(ddpmir_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus
 }

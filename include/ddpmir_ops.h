@@ -41,6 +41,10 @@ int ddpmir_op_gn_scale_shift(const float* x, int B, int HW, int C, int G, const 
 int ddpmir_op_attention(const float* qkv, int B, int N, int C, int heads, float* out);
 /* same through the bf16 matrix-core kernel (fp32 in/out, bf16 operands, fp32 accumulation) */
 int ddpmir_op_attention_bf16(const float* qkv, int B, int N, int C, int heads, float* out);
+/* the same with the routing bound of the no-max kernel (AttnOpts::nm_bound; < 0 = general kernel only) and the routing
+ * counters: stats[0] = general-kernel workgroups that had work, stats[1] = general-kernel workgroups launched beside a
+ * no-max kernel (0 when the shape has no no-max variant) */
+int ddpmir_op_attention_bf16_ex(const float* qkv, int B, int N, int C, int heads, float nm_bound, float* out, int64_t* stats);
 /* conv through the DMA GEMM whose epilogue also accumulates the GroupNorm statistics of its OUTPUT (the next layer's
  * nn.GroupNorm, webp_inference.py:290): sums [B][groups][2] = (sum, sum of squares) per sample and group. */
 int ddpmir_op_conv_gnstats_bf16(const float* x, int B, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,

@@ -103,7 +103,7 @@ def test_fp8_mode_configs4(models):
     operands (per-tensor power-of-two weight scale, unit activation scale) in the 3x3 convolutions with >= 256 input and
     output channels, on v_mfma_scale_f32_32x32x64_f8f6f4.  No reference exists for fp8 arithmetic; the bar is the oracle
     fixture within an fp8 budget (e4m3 carries 3 mantissa bits against bf16's 7, in 20 of the 39 convolutions: measured
-    max 0.09-0.11, mean 6.8-7.3e-3 at 128 ... 512 pixels, tools/fp8_eval.py; budget max 0.25, mean 1.2e-2) and restored
+    max 0.09-0.11, mean 6.8-7.3e-3 at 128 ... 512 pixels, tools/fp8_eval.py; budget 1.5 x that: max 0.17, mean 1.1e-2) and restored
     PSNR equal to bf16 mode's within the scatter of the chaotic loop (measured +0.001 dB over 64 images)."""
     import torch
     from ddpm_image_restoration_amd import harness
@@ -114,14 +114,14 @@ def test_fp8_mode_configs4(models):
     m8 = models(spec.ARCH_JPEG, attn_levels="bottleneck", dtype="fp8")
     y8 = m8(x, tt(g["t"]), tt(g["cl"])).cpu().numpy()
     e8 = np.abs(y8[:, :, ::s, ::s] - g["y"])
-    assert e8.max() < 0.25 and e8.mean() < 1.2e-2, (e8.max(), e8.mean())
+    assert e8.max() < 0.17 and e8.mean() < 1.1e-2, (e8.max(), e8.mean())
     # batch independence and determinism hold in this mode too
     x2 = tt(synth.synth_images(2, 128, seed=5))
     t2 = torch.tensor([0.2, 0.7], device="cuda")
     y2 = m8(x2, t2, t2)
     assert torch.equal(m8(x2, t2, t2), y2)
     d = (m8(x2[1:], t2[1:], t2[1:]) - y2[1:]).abs()
-    assert float(d.max()) < 0.25 and float(d.mean()) < 1.2e-2          # split-K / tiling decisions change with the batch
+    assert float(d.max()) < 0.17 and float(d.mean()) < 1.1e-2          # split-K / tiling decisions change with the batch
     # restored PSNR against bf16 mode: 64 images, 64 x 64, JPEG q20, the harness' 80-step schedule
     x0 = synth.synth_images(64, 64, seed=777)
     yq = harness.COMPRESS[spec.ARCH_JPEG](torch.from_numpy(x0), 20).cuda()

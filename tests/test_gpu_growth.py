@@ -1,0 +1,73 @@
+"""One context driven through GROWING image sizes (the workspace is re-planned and re-allocated at every change,
+Context::ensure_plan) must give what a fresh context gives at that size -- in every arithmetic mode, with attention at
+the bottleneck only (BASELINE configs[4]: the fp8 mode has its own e4m3 operand buffers) and in all blocks.
+
+Regression test for the GPU memory-access fault of round 2 (tools/fp8_eval.py: forwards at 128 x 128, then 256 x 256 on
+the same three contexts; DESIGN.md section 11 has the cause)."""
+import numpy as np
+import pytest
+
+from ddpm_image_restoration_amd import spec, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _fwd(m, size, batch):
+    import torch
+    x = torch.from_numpy(synth.synth_images(batch, size, seed=70 + size)).cuda()
+    t = torch.full((batch,), 0.4, device="cuda")
+    return m(x, t, t)
+
+
+@pytest.mark.parametrize("dtype", ["fp8", "bf16", "f32"])
+def test_context_grows_through_sizes_bottleneck_attention(dtype, synth_state):
+    import torch
+    from ddpm_image_restoration_amd.model import JPEGDiffusionModel
+    sd = synth_state(spec.ARCH_JPEG)
+    dev = torch.device("cuda", 0)
+    grown = JPEGDiffusionModel(device=dev, dtype=dtype, attn_levels="bottleneck")
+    grown.load_state_dict(sd)
+    fresh = None
+    for size, batch in ((64, 2), (128, 2), (256, 2), (512, 1), (128, 3), (256, 2)):   # growing, then shrink + grow again
+        y = _fwd(grown, size, batch)
+        del fresh
+        torch.cuda.empty_cache()
+        fresh = JPEGDiffusionModel(device=dev, dtype=dtype, attn_levels="bottleneck")
+        fresh.load_state_dict(sd)
+        ref = _fwd(fresh, size, batch)
+        assert torch.isfinite(y).all()
+        assert torch.equal(y, ref), (dtype, size, float((y - ref).abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["fp8", "bf16"])
+def test_context_grows_through_sizes_attention_everywhere(dtype, synth_state):
+    import torch
+    from ddpm_image_restoration_amd.model import JPEGDiffusionModel
+    sd = synth_state(spec.ARCH_JPEG)
+    dev = torch.device("cuda", 0)
+    grown = JPEGDiffusionModel(device=dev, dtype=dtype)
+    grown.load_state_dict(sd)
+    for size, batch in ((32, 2), (64, 2), (128, 2), (64, 4), (128, 1)):
+        y = _fwd(grown, size, batch)
+        fresh = JPEGDiffusionModel(device=dev, dtype=dtype)
+        fresh.load_state_dict(sd)
+        ref = _fwd(fresh, size, batch)
+        assert torch.equal(y, ref), (dtype, size, float((y - ref).abs().max()))
+        del fresh
+
+
+@pytest.mark.parametrize("arch", [spec.ARCH_JPEG, spec.ARCH_AVIF])
+def test_blob_size_query_between_forwards_leaves_the_weights_alone(arch, synth_state):
+    """ddpmir_weight_blob_bytes() measures the packed layout by a dry run; asked AFTER finalize_weights it used to re-point
+    the context's weight pointers at offsets from NULL, and the next forward faulted ("Memory access fault by GPU ... on
+    address 0x31000": bench.py queried the size between two sampling calls).  The size is now measured once and cached."""
+    import torch
+    from ddpm_image_restoration_amd.model import MODEL_BY_ARCH
+    m = MODEL_BY_ARCH[arch](device=torch.device("cuda", 0), dtype="bf16")
+    n0 = m.weight_blob_bytes()
+    m.load_state_dict(synth_state(arch))
+    y0 = _fwd(m, 64, 2)
+    assert m.weight_blob_bytes() == n0 and m.param_count() > 1e8
+    assert torch.equal(_fwd(m, 64, 2), y0)
+    assert m.weight_blob_bytes() == n0
+    assert torch.equal(_fwd(m, 32, 1), _fwd(m, 32, 1))

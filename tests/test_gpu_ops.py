@@ -478,6 +478,51 @@ def test_attention_bf16_no_max_and_general_kernels(ops):
             assert e.max() < 3e-2 and e.mean() < 2e-3, (heads, b, e.max(), e.mean())
 
 
+@pytest.mark.parametrize("heads,C,N,B", [(4, 64, 65536, 1), (8, 64, 8192, 2), (4, 128, 4096, 2), (4, 256, 4096, 2)])
+def test_attention_outlier_token_costs_one_query_block(ops, heads, C, N, B):
+    """Routing between the no-max and the general attention kernel is per (batch, head, block of queries): ONE query token
+    with a huge norm per image (what a trained checkpoint may produce) must send only its own block of 128..512 queries to
+    the general kernel -- < 1 % of the workgroups at these sizes -- and the result must still be softmax attention on the
+    bf16-rounded operands, for the outlier row too.  nm_bound < 0 (general kernel everywhere) and the default bound must
+    agree to rounding, and an outlier KEY (which bounds every query of its pair) must fall back pair-wide."""
+    rng = np.random.default_rng(5)
+    d = C // heads
+    qkv = (rng.standard_normal((B, N, 3 * C)) * 0.7).astype(np.float32)
+    out_tok = (37, N - 5)
+    for b in range(B):
+        qkv[b, out_tok[b], :C] *= 400.0                                   # one outlier query token per image, every head
+
+    def bf16(a):
+        u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    got, taken, total = ops.attention_bf16_routed(qkv, heads)
+    # one routing block (= one no-max workgroup = 2 general workgroups at head_dim <= 16, 1 above) per (image, head)
+    assert total > 0 and taken == B * heads * (2 if d <= 16 else 1), (taken, total)
+    if N == 65536:
+        assert taken < 0.01 * total, (taken, total)                       # the full-resolution level of a 256 x 256 forward
+    gen, taken_g, total_g = ops.attention_bf16_routed(qkv, heads, nm_bound=-1.0)
+    assert taken_g == total_g == total
+    assert np.isfinite(got).all() and np.isfinite(gen).all()
+    e = np.abs(got - gen)
+    assert e.max() < 2e-2 and e.mean() < 1e-3, (e.max(), e.mean())
+    # reference on a subset of query rows (the outlier rows, their block neighbours and a few ordinary rows), float64
+    q, k, v = (qkv[..., i * C:(i + 1) * C].reshape(B, N, heads, d).transpose(0, 2, 1, 3) for i in range(3))
+    kr, vr = bf16(k).astype(np.float64), bf16(v).astype(np.float64)
+    for b in range(B):
+        rows = np.array(sorted({out_tok[b], max(out_tok[b] - 1, 0), min(out_tok[b] + 1, N - 1), 0, N // 2, N - 1, 1000}))
+        qr = bf16(q[b][:, rows] * np.float32(1.4426950408889634 / np.sqrt(d))).astype(np.float64)
+        s2 = qr @ kr[b].transpose(0, 2, 1)
+        p = np.exp2(s2 - s2.max(-1, keepdims=True))
+        ref = ((p / p.sum(-1, keepdims=True)) @ vr[b]).transpose(1, 0, 2).reshape(len(rows), C)
+        er = np.abs(got[b, rows] - ref)
+        assert er.max() < 3e-2, (b, er.max())
+    # an outlier key raises the bound of every query of its pair: those pairs run in the general kernel as a whole
+    qkv2 = (rng.standard_normal((1, N, 3 * C)) * 0.7).astype(np.float32)
+    qkv2[0, 11, C:C + d] *= 400.0                                         # head 0 only
+    _, taken2, total2 = ops.attention_bf16_routed(qkv2, heads)
+    assert taken2 == total2 // heads, (taken2, total2)
+
+
 @pytest.mark.parametrize("B,H,W,bs,low,C", [(2, 16, 32, 8, 4, 64), (3, 32, 32, 4, 3, 64), (1, 64, 64, 8, 4, 64), (2, 8, 16, 4, 3, 64),
                                              (2, 16, 24, 8, 4, 128), (3, 16, 16, 4, 3, 128), (1, 32, 64, 8, 4, 128)])
 def test_frequency_block_one_pass_kernel(ops, B, H, W, bs, low, C):
