@@ -41,6 +41,17 @@ __device__ __forceinline__ bool is_low_freq(int y, int x, int H, int W, int bs, 
   return iy < ls && ix < ls;
 }
 
+// four fp32 -> four OCP e4m3 bytes (round to nearest even, clamped to the finite range +-448)
+__device__ __forceinline__ unsigned pack_e4m3x4(float4 v) {
+  const float lim = 448.f;
+  v.x = fminf(fmaxf(v.x, -lim), lim); v.y = fminf(fmaxf(v.y, -lim), lim);
+  v.z = fminf(fmaxf(v.z, -lim), lim); v.w = fminf(fmaxf(v.w, -lim), lim);
+  int r = 0;
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(v.x, v.y, r, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(v.z, v.w, r, true);
+  return (unsigned)r;
+}
+
 struct Status {
   int code = 0;
   std::string msg;

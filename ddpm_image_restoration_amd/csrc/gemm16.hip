@@ -40,17 +40,6 @@ namespace {
 
 constexpr int BM = 128;
 
-// four fp32 -> four OCP e4m3 bytes (round to nearest even, clamped to the finite range +-448)
-__device__ __forceinline__ unsigned pack_e4m3x4(float4 v) {
-  const float lim = 448.f;
-  v.x = fminf(fmaxf(v.x, -lim), lim); v.y = fminf(fmaxf(v.y, -lim), lim);
-  v.z = fminf(fmaxf(v.z, -lim), lim); v.w = fminf(fmaxf(v.w, -lim), lim);
-  int r = 0;
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(v.x, v.y, r, false);
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(v.z, v.w, r, true);
-  return (unsigned)r;
-}
-
 // Epilogue of the DMA GEMM kernels: split-K partial store, or accumulators -> wave-private LDS tile -> fused elementwise work
 // and row-contiguous stores (also the fused qkv packing and the GroupNorm statistics).  acc[nt][r] holds row
 // (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32 rows, column nt * 32 + lr.
@@ -229,17 +218,21 @@ __device__ __forceinline__ void gemm16_epilogue(const IGemm& p, f32x16 (&acc)[NT
       if (p.out8) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.out8) + (size_t)m * p.ldo8 + no) = pack_e4m3x4(v);
     }
     if (p.gn_sums) {
-      // the wave's 32 rows lie in one image (HW % 32 == 0); fold rows (lanes L4 apart), then the lanes of one group
+      // the wave's 32 rows lie in one image (HW % 32 == 0); fold rows (lanes L4 apart), then the lanes of one group.  Every
+      // (32-row wave tile, group) has exactly ONE writer -- a group lies inside one 64-column pass (cpg <= 64) -- which stores
+      // its partial as a double at a slot of its own: no atomics, no clearing pass, and gn_finalize folds the slots of a
+      // (sample, group) in a fixed order, so the statistics are bit-reproducible.
       const int cpg = p.Cout / p.gn_groups, lg = cpg / 4;             // lanes per group within a row segment
 #pragma unroll
       for (int off = L4; off < 64; off <<= 1) { gs1 += __shfl_xor(gs1, off); gs2 += __shfl_xor(gs2, off); }
       const int span = lg < L4 ? lg : L4;
       for (int off = 1; off < span; off <<= 1) { gs1 += __shfl_xor(gs1, off); gs2 += __shfl_xor(gs2, off); }
-      if (rsub == 0 && (c4 % span) == 0) {
-        const int b = (m0 + wave * 32) / HW;
-        double* dst = p.gn_sums + (((size_t)b * GN_SUM_SLOTS + (blockIdx.x & (GN_SUM_SLOTS - 1))) * p.gn_groups + n / cpg) * 2;
-        atomicAdd(dst, (double)gs1);
-        atomicAdd(dst + 1, (double)gs2);
+      const int mw = m0 + wave * 32;
+      if (rsub == 0 && (c4 % span) == 0 && mw < M) {
+        const int b = mw / HW, wt = (mw - b * HW) >> 5;
+        double* dst = p.gn_sums + (((size_t)b * (HW >> 5) + wt) * p.gn_groups + n / cpg) * 2;
+        dst[0] = (double)gs1;
+        dst[1] = (double)gs2;
       }
     }
   }
@@ -288,7 +281,9 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
   const int m0 = bx * BM, n0 = by * (NT * 32);
   const int nck = (p.Cin + BKE - 1) / BKE;
   const int nit_main = p.tap_pack ? (9 + CPR - 1) / CPR : p.taps * nck;
-  const int nit_all = nit_main + (F8 ? 0 : (p.Cinb + BK - 1) / BK);
+  // (F8: the second K segment -- the block's 1x1 shortcut -- stays bf16: its stages use the bf16 fragment reads and MFMA, and
+  //  its weights carry the fp8 weights' power-of-two scale so that one acc_scale undoes both)
+  const int nit_all = nit_main + (p.Cinb + BK - 1) / BK;
   const int nsplit = gridDim.z, sk = blockIdx.z;
   const int it0 = (int)((long long)nit_all * sk / nsplit), it1 = (int)((long long)nit_all * (sk + 1) / nsplit);
   const int nit = (GEMM_DBG(p) & 16) ? 0 : it1 - it0;
@@ -418,7 +413,7 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
     __builtin_amdgcn_s_barrier();
     if (it + AHEAD < nit) issue(it + AHEAD);
     const unsigned char* st = smem + (it % STAGES) * STAGE;
-    if constexpr (F8) {
+    if (F8 && it0 + it < nit_main) {
       // one 32x32x64 MFMA per 64 K bytes of the row: lane half lh holds k = 32 lh .. 32 lh + 31 = chunks 2 lh, 2 lh + 1
       typedef int i32x4 __attribute__((ext_vector_type(4)));
       typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -752,13 +747,13 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
   const bool no_longk = exp_switch("DDPMIR_GEMM_NO_LONGK");   // A/B switch
   const bool longk = !no_longk && p.taps == 9 && (NT <= 2 || ktot >= 2048);
   const bool bk64 = (GEMM_DBG(p) & 32) ? true : (GEMM_DBG(p) & 64) ? false : (tiles < 256 || longk);
-  if (p.f8) {   // fp8 operands: the deep 3x3 convs only (wide N tile); BK = 64 bytes-pairs = 128 K elements per stage
-    if constexpr (NT == 4) {
-      if (bk64) launch_nt<4, 64, 2, 1>(p, M, stream);
-      else launch_nt<4, 32, 2, 1>(p, M, stream);
+  if (p.f8) {   // fp8 operands: the 3x3 convs with >= 64 channels; a stage holds 2 * BK K elements
+    if constexpr (NT >= 2) {
+      if (bk64 && p.Cin >= 128) launch_nt<NT, 64, 2, 1>(p, M, stream);
+      else launch_nt<NT, 32, 2, 1>(p, M, stream);
       return;
     }
-    throw std::runtime_error("gemm16: fp8 operands need Cout > 64");
+    throw std::runtime_error("gemm16: fp8 operands need Cout > 32");
   }
   if constexpr (NT <= 2) {
     // full-resolution 3x3 convs with <= 64 output channels: one strip of pixel rows per kernel row serves its three taps
@@ -777,8 +772,11 @@ bool gemm16_can_fuse_gn(const IGemm& p, int groups) {
   const int64_t M = (int64_t)p.B * p.H * p.W;
   const int NTc = p.Cout <= 32 ? 1 : (p.Cout <= 64 ? 2 : 4);
   const int64_t tiles = cdiv64(M, BM) * cdiv(p.Cout, NTc * 32);
+  // (a group must lie inside one epilogue pass of one workgroup -- 64 columns, 32 for the one-column-tile kernel: channels per
+  //  group a divisor of the pass width, Cout a multiple of it)
+  const int cpg = groups > 0 ? p.Cout / groups : 0, pass = p.Cout <= 32 ? 32 : 64;
   return tiles >= 256 /* never split-K */ && ((p.H * p.W) % 32) == 0 && groups > 0 && (p.Cout % groups) == 0 &&
-         ((p.Cout / groups) % 4) == 0 && !p.pk_q && !p.sel_C && p.out;
+         (cpg % 4) == 0 && cpg <= pass && (pass % cpg) == 0 && (p.Cout % pass) == 0 && !p.pk_q && !p.sel_C && (p.out || p.out16 || p.out8);
 }
 
 bool gemm16_supported(const IGemm& p) {
@@ -787,7 +785,7 @@ bool gemm16_supported(const IGemm& p) {
   return p.A16 && p.Wt16 && p.zero16 && (p.out || p.out16 || p.out8 || p.pk_q) && (!p.out || p.ldo >= (p.sel_C ? p.sel_C : p.Cout)) &&
          (!p.out16 || p.ldo16 > 0) && (!p.out8 || p.ldo8 > 0) && (!p.res || p.ldres > 0) && (!p.mul || p.ldmul > 0) && (!p.tb || p.ldtb > 0) &&
          (p.Cin % al) == 0 && (p.lda16 % al) == 0 && (p.Cout % 4) == 0 &&
-         p.store == STORE_NHWC && p.pro_mask == MASK_NONE && !p.scale && p.pro_act == ACT_NONE && !(p.f8 && (p.Cinb || p.pk_q));
+         p.store == STORE_NHWC && p.pro_mask == MASK_NONE && !p.scale && p.pro_act == ACT_NONE && !(p.f8 && p.pk_q);
 }
 
 void launch_gemm16(const IGemm& p, hipStream_t stream) {

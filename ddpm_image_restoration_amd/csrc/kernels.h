@@ -45,10 +45,11 @@ struct IGemm {
   // [sel_C, 2 sel_C) the high-frequency gate; a row only stores the half that matches its pixel class, at column n mod sel_C
   // (mul / res / out / out16 are indexed with that column; rowscale applies to the high half only)
   int sel_C = 0;
-  // GroupNorm statistics of the OUTPUT tensor accumulated by the epilogue (gemm16.hip, non-split launches): per (sample,
-  // group) sum and sum of squares, fp32 within a wave tile, fp64 atomics across tiles; layout [B][gn_groups][2], zeroed by
-  // the caller.  Saves the separate statistics pass over the tensor (gemm16_can_fuse_gn() says when it applies).
-  double* gn_sums = nullptr; int gn_groups = 0;       // [B][GN_SUM_SLOTS][groups][2], zeroed by the caller
+  // GroupNorm statistics of the OUTPUT tensor emitted by the epilogue (gemm16.hip, non-split launches): per (sample, 32-row
+  // wave tile, group) the sum and the sum of squares (fp32 within the tile, stored as doubles), one writer per slot; layout
+  // [B][H*W/32][gn_groups][2] = gn_sums_doubles() doubles, no clearing needed.  launch_gn_from_sums folds them in a fixed
+  // order.  Saves the separate statistics pass over the tensor (gemm16_can_fuse_gn() says when it applies).
+  double* gn_sums = nullptr; int gn_groups = 0;
   // second K segment (gemm16.hip): a 1x1 operand pair appended after the taps of the first, e.g. the block's 1x1
   // shortcut conv folded into conv_out (out = W_out * S + W_sc * x + (b_out + b_sc)): saves one write + read of `out`
   const void* A16b = nullptr; int lda16b = 0; const void* Wt16b = nullptr; int Cinb = 0;
@@ -71,14 +72,14 @@ void launch_igemm(const IGemm& p, hipStream_t stream);
 void launch_igemm_group(const IGemm* ps, int n, hipStream_t stream);
 bool gemm16_supported(const IGemm& p);
 void launch_gemm16(const IGemm& p, hipStream_t stream);
-// the statistics of one (sample, group) are spread over this many accumulators (picked by the workgroup index) so that the
-// fp64 atomics of thousands of waves do not serialise on one address: with a single accumulator per (sample, group) the 3 -> 64
-// image conv at 512 x 512, B = 8 (65 536 waves, 128 addresses) took 400 us instead of 233 us
-constexpr int GN_SUM_SLOTS = 16;
+inline size_t gn_sums_doubles(int B, int HW, int groups) { return (size_t)B * (size_t)(HW / 32) * groups * 2; }
 bool gemm16_can_fuse_gn(const IGemm& p, int groups);   // p as it will be launched (without gn_sums)
-// fold [B][G][2] fp64 sums (as written by the epilogue above) into per-(b,c) scale / shift
+// fold the [B][HW/32][G][2] partials written by the epilogue above into per-(b,c) scale / shift of a C-channel tensor.
+// scale / shift rows are ldsc floats apart; gamma / beta / scale / shift may point at a channel offset of a wider tensor
+// (the skip half of an up block's concat input gets its statistics from the down block's conv_out this way);
+// zero_to > C: channels [C, zero_to) of every row get scale = shift = 0 (padding channels of the operand pass)
 void launch_gn_from_sums(const double* sums, int B, int HW, int C, int G, const float* gamma, const float* beta, float* scale,
-                         float* shift, hipStream_t stream);
+                         float* shift, hipStream_t stream, int ldsc = 0, int zero_to = 0);
 // fp32 -> bf16 with GroupNorm affine + activation applied once for the consuming conv; optional raw bf16 copy
 // (zero/nzero: optionally clears a small fp64 accumulator, e.g. IGemm::gn_sums of the GEMM that consumes this operand)
 void launch_gn_apply16(const float* x, int ldx, int B, int HW, int C, const float* scale, const float* shift, int act,
@@ -119,8 +120,11 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
 // GroupNorm statistics -> per-(b,c) scale/shift so that norm(x) = x*scale + shift (eps 1e-5, biased var).
 // `partial` is scratch of >= B*G*gn_splits(...)*2 doubles.
 int gn_splits(int HW, int C);
+// ldsc > 0: scale / shift rows are ldsc floats apart and x / gamma / beta / scale / shift may point at a channel offset of a
+// wider tensor (statistics of one half of a concat input); zero_to as in launch_gn_from_sums (default: pad C up to 4)
 void launch_gn_scale_shift(const float* x, int ldx, int B, int HW, int C, int G, const float* gamma,
-                           const float* beta, double* partial, float* scale, float* shift, hipStream_t stream);
+                           const float* beta, double* partial, float* scale, float* shift, hipStream_t stream,
+                           int ldsc = 0, int zero_to = -1);
 
 void launch_maxpool2(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, hipStream_t s);
 void launch_upsample2(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, hipStream_t s);
@@ -142,10 +146,17 @@ bool freq_gate_fused_supported(int B, int H, int W, int C, int bs);
 // (att16 != null: x := W_o att16 + b_o + x is formed inside, i.e. the attention's out_proj + residual rides along)
 void launch_freq_gate_fused(const float* x, const float* dct, const void* w1, const float* b1, const void* w2, const float* b2,
                             const float* boost, void* S16, int B, int H, int W, int C, int bs, int low, hipStream_t s,
-                            const void* att16 = nullptr, const void* wo = nullptr, const float* bo = nullptr);
+                            const void* att16 = nullptr, const void* wo = nullptr, const float* bo = nullptr, void* S8 = nullptr);
+// (S8 != null: S is written as OCP e4m3 there instead of bf16 at S16 -- the operand of an fp8 conv_out)
+// gn_partial_out (mixed 64-channel output, whole blocks, shared matrix: block_transform_gn_fusable): GroupNorm(8) partial sums
+// of the output per (sample, block, group), [B][(H/bs)*(W/bs)][8][2] doubles, for launch_gn_from_partials
 void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int bs,
                             const float* mats, int per_channel, float mix_in, float mix_t, hipStream_t s,
-                            void* low16 = nullptr, void* high16 = nullptr, int low = 0);
+                            void* low16 = nullptr, void* high16 = nullptr, int low = 0, double* gn_partial_out = nullptr);
+bool block_transform_gn_fusable(int H, int W, int C, int bs);
+// fold [B][splits][G][2] double partials (any producer) into per-(b,c) scale / shift; n_per_group = elements per (sample, group)
+void launch_gn_from_partials(const double* partial, int splits, int B, double n_per_group, int C, int G, const float* gamma,
+                             const float* beta, float* scale, float* shift, hipStream_t stream);
 
 // out = a * b * c * d (+ base)   elementwise over [M][C] with per-tensor strides; null pointers are skipped
 // out = base + xt * (0.25 * sum of the four bilinearly upsampled S x S gate maps, S = 1,2,4,8, stored back to back) * col * edge

@@ -10,7 +10,7 @@
 #include "kernels.h"
 
 // layout version of the packed weight blob (layout_weights): bump on any change of order, padding or derived tensors
-#define DDPMIR_WEIGHT_LAYOUT_VERSION 2
+#define DDPMIR_WEIGHT_LAYOUT_VERSION 3
 
 namespace ddpmir {
 
@@ -41,6 +41,8 @@ struct ConvW {          // packed [taps][Cout][CinP] + bias
   // DDPMIR_FP8 contexts, 3x3 convs with >= 256 input and output channels: e4m3 copy [tap][cout16][cin16] of w * 2^k
   // (k = the largest power of two that keeps max|w| * 2^k <= 448) and, in the blob, 2^-k for the epilogue
   void* w8 = nullptr; float* w8_inv_dev = nullptr; float w8_inv = 1.f;
+  int w8_kexp = 0;          // host side, while packing: log2 of the weight scale
+  bool is_f8 = false;       // this conv takes e4m3 operands (valid in the dry-run layout too, where w8 is still null)
 };
 
 struct AvifTransformW {
@@ -59,6 +61,8 @@ struct BlockW {
   float* dct = nullptr;
   ConvW low0, low2, high0, high2;
   float* co_bias = nullptr;   // conv_out.bias + shortcut.bias (shortcut folded into conv_out as a second K segment)
+  void* sc16s = nullptr;      // DDPMIR_FP8, e4m3 conv_out: the shortcut's bf16 weights times conv_out's fp8 weight scale (a power of
+                              // two), so the bf16 second K segment shares the accumulators and the one acc_scale of the fp8 taps
   ConvW fg1, fg2;   // DMA-GEMM path: both gates stacked (C -> [low hid | high hid]) and block-diagonal ([hid] -> [low | high])
   // AVIF frequency block
   AvifTransformW at;
@@ -151,7 +155,8 @@ class Context {
     unsigned char* zero16 = nullptr;
     float* splitk_ws = nullptr;
     double* gn_partial = nullptr;
-    double* gn_sums = nullptr;   // [B][GN_SUM_SLOTS][8][2] statistics accumulated by a GEMM epilogue (conv1 -> norm2)
+    double* gn_sums = nullptr;   // [B][HW/32][8][2] statistics emitted by a GEMM epilogue (conv1 -> norm2)
+    double* skip_sums[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [B][HW_l/32][4][2]: a down block's output -> the up block's norm1
     float *sc1 = nullptr, *sh1 = nullptr, *sc2 = nullptr, *sh2 = nullptr;
     float *hidden = nullptr, *temb = nullptr, *tproj = nullptr;
     float *boost = nullptr, *boost2 = nullptr, *constmix = nullptr;
@@ -179,11 +184,17 @@ class Context {
   void fwd_mid(int B, bool whole, hipStream_t s);
   void fwd_tail(float* out, int row0, int nb, bool whole, hipStream_t s);
   void prof_close_forward(hipStream_t s);
-  void run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
-  void run_block16(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s);
+  // out_stats: a down block leaves the GroupNorm sums of its output there (conv_out's epilogue); in_skip_stats: an up block
+  // takes the statistics of the skip half of its concat input from there instead of reading that half again
+  void run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s,
+                 double* out_stats = nullptr, const double* in_skip_stats = nullptr);
+  void run_block16(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s,
+                   double* out_stats, const double* in_skip_stats);
+  bool skip_stats_fused(int level, int B, int H, int W) const;
   void conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override = nullptr);
   bool use_gemm16() const { return cfg.dtype == DDPMIR_BF16 || cfg.dtype == DDPMIR_FP8; }
-  void conv8(const ConvW& cw, IGemm p, hipStream_t s);   // e4m3 operands (p.A16 = e4m3 tensor)
+  void conv8(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override = nullptr);   // e4m3 operands (p.A16 = e4m3 tensor)
+  int fp8_min_ch_ = 256;    // DDPMIR_FP8: 3x3 convs with at least this many input AND output channels take e4m3 operands
   void freq_dct(const BlockW& bw, int H, int W, hipStream_t s);
   void freq_avif(const BlockW& bw, int H, int W, hipStream_t s);
   void avif_transform(const AvifTransformW& at, const float* x, int ldx, int C, int H, int W, float* T, float* tmp,

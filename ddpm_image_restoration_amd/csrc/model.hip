@@ -113,7 +113,8 @@ void Context::put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name
   cw.w = a.take<float>(n);
   cw.b = a.take<float>(cw.cout16);
   cw.w16 = use_gemm16() ? a.take<unsigned short>(n16) : nullptr;
-  const bool f8 = cfg.dtype == DDPMIR_FP8 && ksz == 3 && cin >= 256 && cout >= 256 && (cin % 16) == 0;
+  const bool f8 = cfg.dtype == DDPMIR_FP8 && ksz == 3 && cin >= fp8_min_ch_ && cout >= fp8_min_ch_ && (cin % 16) == 0 && cout > 32;
+  cw.is_f8 = f8;
   cw.w8 = f8 ? a.take<unsigned char>(n16) : nullptr;
   cw.w8_inv_dev = f8 ? a.take<float>(1) : nullptr;
   n_params_ += (int64_t)cout * cin * cw.taps + cout;
@@ -147,6 +148,7 @@ void Context::put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name
     for (float v : packed) amax = std::max(amax, std::fabs(v));
     const int kexp = amax > 0.f ? (int)std::floor(std::log2(448.0 / (double)amax)) : 0;
     const float sw = std::ldexp(1.0f, kexp), inv = std::ldexp(1.0f, -kexp);
+    cw.w8_kexp = kexp;
     std::vector<unsigned char> p8(n16, 0);
     for (int t = 0; t < cw.taps; ++t)
       for (int o = 0; o < cout; ++o)
@@ -277,6 +279,23 @@ void Context::layout_weights(Arena& a, bool up) {
     }
     put_conv(a, up, b.conv_out, fg + ".conv_out", d.cout, d.cout, 3);
     if (b.has_shortcut) put_conv(a, up, b.shortcut, n + ".shortcut", d.cout, d.cin, 1);
+    if (b.has_shortcut && b.conv_out.is_f8) {   // bf16 shortcut weights on conv_out's fp8 scale (second K segment of the e4m3 conv_out)
+      const size_t nsc = (size_t)b.shortcut.cout16 * b.shortcut.cin16;
+      b.sc16s = a.take<unsigned short>(nsc);
+      if (up) {
+        const auto& w = host_.at(std::string(d.name) + ".shortcut.weight").data;   // [cout][cin] (1x1)
+        const float sw = std::ldexp(1.0f, b.conv_out.w8_kexp);
+        std::vector<unsigned short> ws(nsc, 0);
+        for (int o = 0; o < d.cout; ++o)
+          for (int c = 0; c < d.cin; ++c) {
+            const float f = w[(size_t)o * d.cin + c] * sw;
+            unsigned int u;
+            std::memcpy(&u, &f, 4);
+            ws[(size_t)o * b.shortcut.cin16 + c] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+          }
+        DDPMIR_HIP_CHECK(hipMemcpy(b.sc16s, ws.data(), nsc * 2, hipMemcpyHostToDevice));
+      }
+    }
     if (b.has_shortcut && use_gemm16()) {
       b.co_bias = a.take<float>(d.cout);
       if (up) {
@@ -387,7 +406,7 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
     if (cfg.dtype == DDPMIR_FP8) {
       size_t m8 = 0;   // largest e4m3 operand: pixels * channels over the blocks that have fp8 convs (C >= 256: levels >= 2)
       for (auto& d : kBlocks)
-        if (d.cout >= 256) m8 = std::max(m8, (size_t)B * hw(d.level) * (size_t)std::max(d.cin, d.cout));
+        if (d.cout >= fp8_min_ch_) m8 = std::max(m8, (size_t)B * hw(d.level) * (size_t)std::max(d.cin, d.cout));
       p.a8 = a.take<unsigned char>(m8 + 16); p.S8 = a.take<unsigned char>(m8 + 16);
     }
     p.zero16 = a.take<unsigned char>(GEMM16_ZERO_BYTES);
@@ -395,7 +414,8 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
   }
   int max_splits = gn_splits(H * W, 64);
   p.gn_partial = a.take<double>((size_t)B * 8 * max_splits * 2 + 64);
-  p.gn_sums = a.take<double>((size_t)B * GN_SUM_SLOTS * 8 * 2 + 64);
+  p.gn_sums = a.take<double>(2 * gn_sums_doubles(B, H * W, 8) + 64);   // (x2: the head's per-4x4-block partials, H*W/16 slots)
+  for (int l = 0; l < 5; ++l) p.skip_sums[l] = use_gemm16() ? a.take<double>(gn_sums_doubles(B, (int)hw(l), 4) + 64) : nullptr;
   p.sc1 = a.take<float>((size_t)B * 1024); p.sh1 = a.take<float>((size_t)B * 1024);
   p.sc2 = a.take<float>((size_t)B * 1024); p.sh2 = a.take<float>((size_t)B * 1024);
   p.hidden = a.take<float>((size_t)B * 1024); p.temb = a.take<float>((size_t)B * 256);
@@ -567,6 +587,13 @@ void Context::set_option(const std::string& name, double value) {
     if (plan_.graph) { (void)hipGraphDestroy(plan_.graph); plan_.graph = nullptr; }
     return;
   }
+  if (name == "fp8_min_channels") {   // DDPMIR_FP8: which 3x3 convs take e4m3 operands (before the weights are loaded: it sizes the blob)
+    if (finalized_) throw std::logic_error("fp8_min_channels must be set before finalize_weights");
+    if (value != 64 && value != 128 && value != 256) throw std::invalid_argument("fp8_min_channels must be 64, 128 or 256");
+    fp8_min_ch_ = (int)value;
+    blob_bytes_ = 0;
+    return;
+  }
   throw std::invalid_argument("unknown option " + name);
 }
 
@@ -690,12 +717,12 @@ void Context::conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_
   prof_end(s);
 }
 
-void Context::conv8(const ConvW& cw, IGemm p, hipStream_t s) {
-  p.Wt = nullptr; p.Wt16 = cw.w8; p.bias = cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
+void Context::conv8(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override) {
+  p.Wt = nullptr; p.Wt16 = cw.w8; p.bias = bias_override ? bias_override : cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
   p.f8 = 1; p.acc_scale = cw.w8_inv;
   p.zero16 = plan_.zero16; p.splitk_ws = plan_.splitk_ws; p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
   if (!gemm16_supported(p)) throw std::logic_error("conv8: operand layout not supported by the fp8 GEMM");
-  prof_begin(PROF_GEMM8, 2.0 * (double)p.B * p.H * p.W * (double)cw.cout * cw.cin * cw.taps, s);
+  prof_begin(PROF_GEMM8, 2.0 * (double)p.B * p.H * p.W * ((double)cw.cout * cw.cin * cw.taps + (p.Cinb ? (double)cw.cout * p.Cinb : 0.0)), s);
   launch_gemm16(p, s);
   prof_end(s);
 }
@@ -704,14 +731,22 @@ void Context::conv8(const ConvW& cw, IGemm p, hipStream_t s) {
 // previous GEMM epilogue, attention, DCT kernel), so both GEMM operands stream by LDS-DMA (gemm16.hip).
 // The fp32 tensors that carry the residual stream and the GroupNorm statistics stay fp32.
 void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest,
-                          hipStream_t s) {
+                          hipStream_t s, double* out_stats, const double* in_skip_stats) {
   Plan& p = plan_;
   const int B = fb_, C = bw.cout, HW = H * W;
   const int cin8 = round_up(bw.cin, 8);
 #define STAGE(what) debug_stage(s, bw.name.c_str(), what, B, H, W, C)
   IGemm g; g.B = B; g.H = H; g.W = W; g.bs = k.dct_block; g.low = k.low_size;
   // norm1 -> conv1 (+ bias + time projection)
-  launch_gn_scale_shift(in, ldin, B, HW, bw.cin, gn_groups(bw.cin), bw.n1g, bw.n1b, p.gn_partial, p.sc1, p.sh1, s);
+  if (in_skip_stats) {
+    // up block: the input is cat[upsampled, skip] and its 8 groups split 4 + 4 over the halves.  The skip half's sums came out
+    // of the down block's conv_out epilogue (no pass over that half); only the upsampled half is read here.
+    const int ch = bw.cin / 2, ld = round_up(bw.cin, 4);
+    launch_gn_scale_shift(in, ldin, B, HW, ch, 4, bw.n1g, bw.n1b, p.gn_partial, p.sc1, p.sh1, s, ld, 0);
+    launch_gn_from_sums(in_skip_stats, B, HW, ch, 4, bw.n1g + ch, bw.n1b + ch, p.sc1 + ch, p.sh1 + ch, s, ld, 0);
+  } else {
+    launch_gn_scale_shift(in, ldin, B, HW, bw.cin, gn_groups(bw.cin), bw.n1g, bw.n1b, p.gn_partial, p.sc1, p.sh1, s);
+  }
   STAGE("norm1 statistics");
   // (3-channel image input: x4 carries a zero 4th channel, gn_finalize zeroes its scale/shift, a16 pads to 8)
   IGemm c1 = g; c1.A16 = p.a16; c1.lda16 = cin8; c1.tb = p.tproj + bw.tproj_off; c1.ldtb = nt_total_;
@@ -724,7 +759,7 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   // (DDPMIR_FP8: the deep 3x3 convs take their operand as e4m3 instead -- written by the same pass)
   const bool c1_f8 = bw.conv1.w8 != nullptr, c2_f8 = bw.conv2.w8 != nullptr, co_f8 = bw.conv_out.w8 != nullptr;
   launch_gn_apply16(in, ldin, B, HW, bw.cinp, p.sc1, p.sh1, ACT_NONE, c1_f8 ? nullptr : p.a16, cin8, bw.has_shortcut ? p.x16 : nullptr,
-                    cin8, s, fuse_gn ? p.gn_sums : nullptr, fuse_gn ? B * GN_SUM_SLOTS * gn_groups(C) * 2 : 0, c1_f8 ? p.a8 : nullptr, bw.conv1.cin16);
+                    cin8, s, nullptr, 0, c1_f8 ? p.a8 : nullptr, bw.conv1.cin16);
   STAGE("norm1 apply");
   if (fuse_gn) { c1.gn_sums = p.gn_sums; c1.gn_groups = gn_groups(C); }
   if (c1_f8) { c1.A16 = p.a8; c1.lda16 = bw.conv1.cin16; conv8(bw.conv1, c1, s); }
@@ -739,8 +774,8 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   STAGE("norm2 apply + GELU");
   const bool attn = bw.level >= cfg.attn_min_level;
   // 64- and 128-channel blocks of the DCT families: DCT, both gate layers and S = x + g * xd run as one pass over x
-  const bool fuse_freq = cfg.arch != DDPMIR_ARCH_AVIF && !exp_switch("DDPMIR_SPLIT_GATES") && !co_f8 && !exp_switch("DDPMIR_NO_FREQ_FUSE") &&
-                         freq_gate_fused_supported(B, H, W, C, k.dct_block);
+  const bool fuse_freq = cfg.arch != DDPMIR_ARCH_AVIF && !exp_switch("DDPMIR_SPLIT_GATES") && !exp_switch("DDPMIR_NO_FREQ_FUSE") &&
+                         freq_gate_fused_supported(B, H, W, C, k.dct_block);   // (e4m3 conv_out: the kernel writes S as e4m3)
   IGemm c2 = g; c2.A16 = p.a16; c2.lda16 = C; c2.out = p.hB; c2.ldo = C;
   if (attn) { c2.out16 = p.hB16; c2.ldo16 = C; }
   if (c2_f8) { c2.A16 = p.a8; conv8(bw.conv2, c2, s); }
@@ -789,8 +824,8 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
                       co_f8 ? p.S8 : nullptr, C);
   } else if (fuse_freq) {
     // (freq_fused.hip; with attention in the block, x = out_proj(att) + x is formed there too)
-    launch_freq_gate_fused(p.hB, bw.dct, bw.fg1.w16, bw.fg1.b, bw.fg2.w16, bw.fg2.b, p.boost, p.S16, B, H, W, C, k.dct_block,
-                           k.low_size, s, attn && C == 64 ? p.att16 : nullptr, bw.out_proj.w16, bw.out_proj.b);
+    launch_freq_gate_fused(p.hB, bw.dct, bw.fg1.w16, bw.fg1.b, bw.fg2.w16, bw.fg2.b, p.boost, co_f8 ? nullptr : p.S16, B, H, W, C, k.dct_block,
+                           k.low_size, s, attn && C == 64 ? p.att16 : nullptr, bw.out_proj.w16, bw.out_proj.b, co_f8 ? p.S8 : nullptr);
   } else if (!split_gates) {
     launch_block_transform(p.hB, C, p.xd, C, B, H, W, C, k.dct_block, bw.dct, 0, 0.f, 1.f, s, p.xdl16, nullptr, k.low_size);
     IGemm a = g; a.A16 = p.xdl16; a.lda16 = C; a.epi_act = ACT_LRELU; a.out16 = p.hid16; a.ldo16 = C;
@@ -816,18 +851,19 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   // conv_out + residual; a 1x1 shortcut conv rides along as a second K segment of the same GEMM (identity shortcuts
   // are the plain fp32 residual)
   IGemm co = g; co.A16 = p.S16; co.lda16 = C; co.out = dest; co.ldo = lddest;
+  if (out_stats) { co.gn_sums = out_stats; co.gn_groups = 4; }   // a down block's output is the skip half of an up block's norm1
   const bool split_sc = exp_switch("DDPMIR_SPLIT_SHORTCUT");   // A/B: separate shortcut GEMM
   if (co_f8) {
-    // e4m3 conv_out: a bf16 1x1 shortcut cannot share the MFMA type, so it runs as its own GEMM and comes back as residual
+    // e4m3 conv_out: the bf16 1x1 shortcut still rides along as the second K segment -- its stages run on the bf16 MFMA into the
+    // same accumulators, with weights pre-multiplied by conv_out's power-of-two fp8 weight scale (BlockW::sc16s)
+    co.A16 = p.S8;
     if (bw.has_shortcut) {
-      IGemm sc = g; sc.A16 = p.x16; sc.lda16 = cin8; sc.out = dest; sc.ldo = lddest;
-      conv16(bw.shortcut, sc, s);
-      co.res = dest; co.ldres = lddest;
+      co.A16b = p.x16; co.lda16b = cin8; co.Wt16b = bw.sc16s; co.Cinb = bw.shortcut.cin16;
+      conv8(bw.conv_out, co, s, bw.co_bias);
     } else {
       co.res = in; co.ldres = ldin;
+      conv8(bw.conv_out, co, s);
     }
-    co.A16 = p.S8;
-    conv8(bw.conv_out, co, s);
   } else if (bw.has_shortcut && !split_sc) {
     co.A16b = p.x16; co.lda16b = cin8; co.Wt16b = bw.shortcut.w16; co.Cinb = bw.shortcut.cin16;
     conv16(bw.conv_out, co, s, bw.co_bias);
@@ -845,9 +881,19 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
 #undef STAGE
 }
 
+// Can the down block at `level` emit the GroupNorm sums of its output (the skip half of the matching up block's norm1 input)
+// from conv_out's epilogue?  Decided from shapes alone, so the down and the up block agree.
+bool Context::skip_stats_fused(int level, int B, int H, int W) const {
+  if (!use_gemm16() || level > 4 || exp_switch("DDPMIR_NO_SKIP_STATS")) return false;
+  const BlockW& bw = blocks_[level];
+  IGemm probe; probe.B = B; probe.H = H; probe.W = W; probe.Cout = bw.conv_out.cout16; probe.Cin = bw.conv_out.cin16; probe.taps = 9;
+  probe.out = plan_.hA;   // (any non-null output)
+  return gemm16_can_fuse_gn(probe, 4);
+}
+
 void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest,
-                        hipStream_t s) {
-  if (use_gemm16()) { run_block16(bw, in, ldin, H, W, dest, lddest, s); return; }
+                        hipStream_t s, double* out_stats, const double* in_skip_stats) {
+  if (use_gemm16()) { run_block16(bw, in, ldin, H, W, dest, lddest, s, out_stats, in_skip_stats); return; }
   Plan& p = plan_;
   const int B = fb_, C = bw.cout;
   IGemm g; g.B = B; g.H = H; g.W = W;
@@ -936,7 +982,8 @@ void Context::fwd_head(const float* x, const float* t, const float* cl, int row0
     SideRows rows(p.tproj, p.boost, p.boost2, p.constmix, row0, nt_total_);
     // the skip tensor goes straight into the second half of up5's concat buffer
     debug_stage(s, "forward", "image layout + time embedding", nb, H, W, 3);
-    run_block(blocks_[0], x4, 4, H, W, p.cat[0] + (size_t)row0 * HW * 128 + 64, 128, s);
+    double* st0 = skip_stats_fused(0, nb, H, W) ? p.skip_sums[0] + gn_sums_doubles(row0, (int)HW, 4) : nullptr;
+    run_block(blocks_[0], x4, 4, H, W, p.cat[0] + (size_t)row0 * HW * 128 + 64, 128, s, st0);
   }
   if (!whole) prof_close_forward(s);
 }
@@ -957,7 +1004,7 @@ void Context::fwd_mid(int B, bool whole, hipStream_t s) {
   const float* in = p.pin[1]; int ldin = skip_c[0];
   for (int l = 1; l < 5; ++l) {
     float* d = p.cat[l] + skip_off[l];
-    run_block(blocks_[l], in, ldin, hh(l), ww(l), d, cat_c[l], s);
+    run_block(blocks_[l], in, ldin, hh(l), ww(l), d, cat_c[l], s, skip_stats_fused(l, B, hh(l), ww(l)) ? p.skip_sums[l] : nullptr);
     launch_maxpool2(d, cat_c[l], p.pin[l + 1], skip_c[l], B, hh(l), ww(l), skip_c[l], s);
     debug_stage(s, "forward", "max-pool", B, hh(l), ww(l), skip_c[l]);
     in = p.pin[l + 1]; ldin = skip_c[l];
@@ -971,7 +1018,8 @@ void Context::fwd_mid(int B, bool whole, hipStream_t s) {
     launch_upsample2(prev, prev_c, p.cat[l], cat_c[l], B, hh(l + 1), ww(l + 1), prev_c, s);
     debug_stage(s, "forward", "bilinear x2", B, hh(l + 1), ww(l + 1), prev_c);
     const BlockW& bw = blocks_[8 + (4 - l)];
-    run_block(bw, p.cat[l], cat_c[l], hh(l), ww(l), p.u[l], bw.cout, s);
+    run_block(bw, p.cat[l], cat_c[l], hh(l), ww(l), p.u[l], bw.cout, s, nullptr,
+              skip_stats_fused(l, B, hh(l), ww(l)) ? p.skip_sums[l] : nullptr);
     prev = p.u[l]; prev_c = bw.cout;
   }
   if (!whole) prof_close_forward(s);
@@ -989,13 +1037,21 @@ void Context::fwd_tail(float* out, int row0, int nb, bool whole, hipStream_t s) 
   float* cat0 = p.cat[0] + (size_t)row0 * HW * 128;
   float* u0 = p.u[0] + (size_t)row0 * HW * bw.cout;
   launch_upsample2(p.u[1] + (size_t)row0 * (HW / 4) * prev_c, prev_c, cat0, 128, nb, H >> 1, W >> 1, prev_c, s);
-  run_block(bw, cat0, 128, H, W, u0, bw.cout, s);
+  run_block(bw, cat0, 128, H, W, u0, bw.cout, s, nullptr,
+            skip_stats_fused(0, nb, H, W) ? p.skip_sums[0] + gn_sums_doubles(row0, (int)HW, 4) : nullptr);
   // head: u5 + mix * transform(u5) -> GroupNorm(8) -> SiLU -> conv 64->3 -> tanh     webp_inference.py:396-399
+  const bool head_gn_fused = use_gemm16() && cfg.arch != DDPMIR_ARCH_AVIF && block_transform_gn_fusable(H, W, 64, k.dct_block) &&
+                             !exp_switch("DDPMIR_NO_HEAD_GN_FUSE");
   if (cfg.arch == DDPMIR_ARCH_AVIF)
     avif_transform(head_at_, u0, 64, 64, H, W, p.xd, p.hid, p.S, 64, p.constmix, u0, 64, s);
   else
-    launch_block_transform(u0, 64, p.S, 64, nb, H, W, 64, k.dct_block, head_dct_, 0, 1.0f, k.head_mix, s);
-  launch_gn_scale_shift(p.S, 64, nb, H * W, 64, 8, head_g_, head_b_, p.gn_partial, p.sc1, p.sh1, s);
+    launch_block_transform(u0, 64, p.S, 64, nb, H, W, 64, k.dct_block, head_dct_, 0, 1.0f, k.head_mix, s, nullptr, nullptr, 0,
+                           head_gn_fused ? p.gn_sums : nullptr);
+  // (DCT families, bf16 / fp8 mode: the mix pass also emits the GroupNorm sums of its output)
+  if (head_gn_fused)
+    launch_gn_from_partials(p.gn_sums, (H / k.dct_block) * (W / k.dct_block), nb, (double)H * W * 8, 64, 8, head_g_, head_b_, p.sc1, p.sh1, s);
+  else
+    launch_gn_scale_shift(p.S, 64, nb, H * W, 64, 8, head_g_, head_b_, p.gn_partial, p.sc1, p.sh1, s);
   if (use_gemm16()) {   // SiLU(GN(.)) as a bf16 operand -> DMA GEMM with Cout padded to 4 -> tanh + NCHW in one pass
     float* x4 = p.x4 + (size_t)row0 * HW * 4;          // the lane's image rows are free again
     launch_gn_apply16(p.S, 64, nb, H * W, 64, p.sc1, p.sh1, ACT_SILU, p.a16, 64, nullptr, 0, s);

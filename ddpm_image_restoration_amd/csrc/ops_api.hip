@@ -77,7 +77,7 @@ int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_
         for (int t = 0; t < taps; ++t) wp[((size_t)t * Cout + o) * cinp + c] = w_oihw[((size_t)o * Cin + c) * taps + t];
     if (g_bf16 == 3) {
       // fp8 variant of the DMA GEMM: x -> e4m3 by the operand pass, weights -> e4m3 with a per-tensor power-of-two scale
-      if (pro_mask != MASK_NONE || nchw_out || (Cout % 4) != 0 || (Cin % 16) != 0 || Cout <= 64) throw std::runtime_error("fp8 gemm op: unsupported shape");
+      if (pro_mask != MASK_NONE || nchw_out || (Cout % 4) != 0 || (Cin % 16) != 0 || Cout <= 32) throw std::runtime_error("fp8 gemm op: unsupported shape");
       float amax = 0.f;
       for (float v : wp) amax = std::max(amax, std::fabs(v));
       const int kexp = amax > 0.f ? (int)std::floor(std::log2(448.0 / (double)amax)) : 0;
@@ -198,7 +198,7 @@ int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int b
       gelu_norm = 0;
     }
     if (bf16 == 3) {   // fp8 variant of the gemm16 path: e4m3 A tensor and weights made once outside the timed region
-      if (Cin % 16 || Cout <= 64) throw std::runtime_error("fp8 gemm timing needs Cin % 16 == 0 and Cout > 64");
+      if (Cin % 16 || Cout <= 32) throw std::runtime_error("fp8 gemm timing needs Cin % 16 == 0 and Cout > 32");
       unsigned char* a8 = d.alloc<unsigned char>(M * Cin + 16);
       launch_gn_apply16(x, Cin, B, H * W, Cin, nullptr, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, a8, Cin);
       std::vector<unsigned char> w8(wh.size());
@@ -255,16 +255,17 @@ int ddpmir_op_conv_gnstats_bf16(const float* x, int B, int H, int W, int Cin, co
     float* o = d.alloc<float>(M * Cout);
     p.out = o; p.ldo = Cout;
     if (!gemm16_can_fuse_gn(p, groups)) throw std::runtime_error("conv_gnstats: shape cannot fuse the statistics");
-    double* ds = d.alloc<double>((size_t)B * GN_SUM_SLOTS * groups * 2);
+    const size_t nw = (size_t)(H * W / 32);                    // one partial per (sample, 32-row wave tile, group)
+    double* ds = d.alloc<double>(gn_sums_doubles(B, H * W, groups));
     p.gn_sums = ds; p.gn_groups = groups;
     launch_gemm16(p, nullptr);
     d.down(out, o, M * Cout);
-    std::vector<double> slots((size_t)B * GN_SUM_SLOTS * groups * 2);
+    std::vector<double> slots(gn_sums_doubles(B, H * W, groups));
     d.down(slots.data(), ds, slots.size());
-    for (int b = 0; b < B; ++b)            // fold the accumulator slots of every (sample, group)
+    for (int b = 0; b < B; ++b)            // fold the wave-tile partials of every (sample, group)
       for (int g = 0; g < groups * 2; ++g) {
         double t = 0.0;
-        for (int sl = 0; sl < GN_SUM_SLOTS; ++sl) t += slots[((size_t)b * GN_SUM_SLOTS + sl) * groups * 2 + g];
+        for (size_t sl = 0; sl < nw; ++sl) t += slots[((size_t)b * nw + sl) * groups * 2 + g];
         sums[(size_t)b * groups * 2 + g] = t;
       }
   });

@@ -105,32 +105,38 @@ __global__ __launch_bounds__(256) void gn_partial_group(const float* __restrict_
   }
 }
 
-// one 64-lane wave per (sample, group): strided sum of the double partials, wave reduction, then the group's
-// channels (and, from the last group, the padded channels Cs > C) get their folded scale / shift
-__global__ __launch_bounds__(64) void gn_finalize(const double* __restrict__ partial, int splits, int HW, int C, int Cs,
-                                                  int G, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  float* __restrict__ scale, float* __restrict__ shift) {
-  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+// one workgroup per (sample, group): strided sum of the double partials in a FIXED order (thread t takes slots t, t + 256, ...;
+// wave shuffle tree; the four wave sums in order), then the group's channels get their folded scale / shift.  The order does
+// not depend on how the partials were produced, so GroupNorm statistics are bit-reproducible run to run.
+// n_per_group = elements behind one group's sums; scale / shift rows are ldsc floats apart; channels [C, zero_to) are zeroed.
+__global__ __launch_bounds__(256) void gn_finalize(const double* __restrict__ partial, int splits, double n_per_group, int C, int ldsc,
+                                                   int G, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float* __restrict__ scale, float* __restrict__ shift, int zero_to) {
+  __shared__ double r1[4], r2[4];
+  const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
   const int cpg = C / G;
   double t1 = 0.0, t2 = 0.0;
-  for (int s = lane; s < splits; s += 64) {
+  for (int s = tid; s < splits; s += 256) {
     const double* o = partial + (((size_t)b * splits + s) * G + g) * 2;
     t1 += o[0]; t2 += o[1];
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { t1 += __shfl_xor(t1, off); t2 += __shfl_xor(t2, off); }
-  const double n = (double)HW * cpg;
-  const double mean = t1 / n;
-  double var = t2 / n - mean * mean;
+  if ((tid & 63) == 0) { r1[tid >> 6] = t1; r2[tid >> 6] = t2; }
+  __syncthreads();
+  t1 = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+  t2 = (r2[0] + r2[1]) + (r2[2] + r2[3]);
+  const double mean = t1 / n_per_group;
+  double var = t2 / n_per_group - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+  for (int c = g * cpg + tid; c < (g + 1) * cpg; c += 256) {
     const float sc = rstd * gamma[c];
-    scale[(size_t)b * Cs + c] = sc;
-    shift[(size_t)b * Cs + c] = beta[c] - (float)mean * sc;
+    scale[(size_t)b * ldsc + c] = sc;
+    shift[(size_t)b * ldsc + c] = beta[c] - (float)mean * sc;
   }
   if (g == G - 1)
-    for (int c = C + lane; c < Cs; c += 64) { scale[(size_t)b * Cs + c] = 0.f; shift[(size_t)b * Cs + c] = 0.f; }
+    for (int c = C + tid; c < zero_to; c += 256) { scale[(size_t)b * ldsc + c] = 0.f; shift[(size_t)b * ldsc + c] = 0.f; }
 }
 
 // ------------------------------------------------------------------------------------------- resampling
@@ -343,11 +349,14 @@ __global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_k(const f
 // for the runtime mix and carries the mask logic: 206 VGPRs / 2 waves per SIMD at BS = 8 and 208 us for the level-0 tensor
 // (B = 16, 256 x 256 x 64) against 119 us for this mapping stand-alone (tools/micro/dct_store.hip, 5.6 TB/s; wider
 // per-thread accesses -- two channels per thread, an LDS-staged patch with 16-byte I/O -- measured SLOWER there).
+// gnp != null (the head's mix, C = 64): also emits the GroupNorm(8) partial sums of the OUTPUT, one (sum, sum of squares) per
+// (sample, block, group) at gnp[((b * blocks_per_image + block) * 8 + group) * 2] -- the statistics pass over the mixed tensor
+// (one more read of 537 MB at 512 x 512, B = 8) disappears; gn_finalize folds the slots in a fixed order.
 template <int BS, bool PC, bool O16, bool MIX = false>
 __global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_fast_k(const float* __restrict__ in, int ldi, float* __restrict__ out,
                                                                              int ldo, int B, int H, int W, int C,
                                                                              const float* __restrict__ mats, __bf16* __restrict__ o16,
-                                                                             float mix_in, float mix_t) {
+                                                                             float mix_in, float mix_t, double* __restrict__ gnp) {
   __shared__ float Ts[BS * BS];
   if (!PC) {
     for (int i = threadIdx.x; i < BS * BS; i += blockDim.x) Ts[i] = mats[i];
@@ -363,6 +372,7 @@ __global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_fast_k(co
     const int b = (int)(p / nby);
     const float* T = PC ? mats + (size_t)c * BS * BS : Ts;
     const size_t base = (((size_t)b * H + by * BS) * W + bx * BS);
+    float gs1 = 0.f, gs2 = 0.f;
     float X[BS][BS];
 #pragma unroll
     for (int u = 0; u < BS; ++u)
@@ -396,6 +406,16 @@ __global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_fast_k(co
         if (MIX) a = mix_in * X[u][v] + mix_t * a;       // the head's u5 + 0.1 DCT(u5) (webp_inference.py:396)
         out[o * ldo + c] = a;
         if (O16) o16[o * C + c] = (__bf16)a;
+        if (MIX) { gs1 += a; gs2 = fmaf(a, a, gs2); }
+      }
+    }
+    if (MIX && gnp) {   // C = 64 (host check): the 8 channels of a group are 8 consecutive lanes
+      double d1 = (double)gs1, d2 = (double)gs2;
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); }
+      if ((c & 7) == 0) {
+        double* dst = gnp + ((((size_t)b * nby + by) * nbx + bx) * 8 + (c >> 3)) * 2;
+        dst[0] = d1; dst[1] = d2;
       }
     }
   }
@@ -573,9 +593,10 @@ int gn_splits(int HW, int C) {
 }
 
 void launch_gn_scale_shift(const float* x, int ldx, int B, int HW, int C, int G, const float* gamma,
-                           const float* beta, double* partial, float* scale, float* shift, hipStream_t stream) {
+                           const float* beta, double* partial, float* scale, float* shift, hipStream_t stream, int ldsc, int zero_to) {
   // scale/shift rows are padded to a multiple of 4 channels (zeros) so igemm can read float4
-  const int Cs = round_up(C, 4);
+  const int Cs = ldsc > 0 ? ldsc : round_up(C, 4);
+  if (zero_to < 0) zero_to = ldsc > 0 ? 0 : Cs;
   if (C > 1024) throw std::runtime_error("group norm: C > 1024 unsupported");
   const int cpg = C / G;
   const bool by_group = cpg >= 32 && (cpg % 4) == 0 && cpg <= 1024 && (ldx % 4) == 0;
@@ -585,14 +606,16 @@ void launch_gn_scale_shift(const float* x, int ldx, int B, int HW, int C, int G,
     hipLaunchKernelGGL(gn_partial_group, dim3(G * splits, B), dim3(256), 0, stream, x, ldx, HW, C, G, splits, partial);
   else
     hipLaunchKernelGGL(gn_partial, dim3(splits, B), dim3(256), 0, stream, x, ldx, HW, C, G, splits, partial);
-  hipLaunchKernelGGL(gn_finalize, dim3(G, B), dim3(64), 0, stream, partial, splits, HW, C, Cs, G,
-                     gamma, beta, scale, shift);
+  hipLaunchKernelGGL(gn_finalize, dim3(G, B), dim3(256), 0, stream, partial, splits, (double)HW * (C / G), C, Cs, G,
+                     gamma, beta, scale, shift, zero_to);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
 void launch_gn_from_sums(const double* sums, int B, int HW, int C, int G, const float* gamma, const float* beta, float* scale,
-                         float* shift, hipStream_t stream) {
-  hipLaunchKernelGGL(gn_finalize, dim3(G, B), dim3(64), 0, stream, sums, GN_SUM_SLOTS, HW, C, round_up(C, 4), G, gamma, beta, scale, shift);
+                         float* shift, hipStream_t stream, int ldsc, int zero_to) {
+  const int Cs = ldsc > 0 ? ldsc : round_up(C, 4);
+  hipLaunchKernelGGL(gn_finalize, dim3(G, B), dim3(256), 0, stream, sums, HW / 32, (double)HW * (C / G), C, Cs, G, gamma, beta,
+                     scale, shift, ldsc > 0 ? zero_to : Cs);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
@@ -638,14 +661,16 @@ void launch_pool_from8(const float* sums, float* out, int ldo, int B, int H, int
 
 void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int bs,
                             const float* mats, int per_channel, float mix_in, float mix_t, hipStream_t s,
-                            void* low16, void* high16, int low) {
+                            void* low16, void* high16, int low, double* gn_partial_out) {
   int64_t total = (int64_t)B * cdiv(H, bs) * cdiv(W, bs) * C;
   __bf16* l16 = reinterpret_cast<__bf16*>(low16);
   __bf16* h16 = reinterpret_cast<__bf16*>(high16);
   if ((H % bs) == 0 && (W % bs) == 0 && !h16 && (bs == 4 || bs == 8)) {
     auto go = [&](auto kern, int block) {
-      hipLaunchKernelGGL(kern, dim3(grid_for(total, block)), dim3(block), 0, s, in, ldi, out, ldo, B, H, W, C, mats, l16, mix_in, mix_t);
+      hipLaunchKernelGGL(kern, dim3(grid_for(total, block)), dim3(block), 0, s, in, ldi, out, ldo, B, H, W, C, mats, l16, mix_in, mix_t,
+                         gn_partial_out);
     };
+    if (gn_partial_out && (C != 64 || mix_in == 0.f)) throw std::runtime_error("block transform: fused GroupNorm sums need the 64-channel mixed output");
     if (!(mix_in == 0.f && mix_t == 1.f)) {   // mixed output: the model's head only (shared matrix, no bf16 copy)
       if (per_channel || l16) goto general;
       if (bs == 4) go(block_transform_fast_k<4, false, false, true>, 256);
@@ -669,6 +694,16 @@ general:
                        C, mats, per_channel, mix_in, mix_t, l16, h16, low);
   else
     throw std::runtime_error("block transform: block size must be 4 or 8");
+  if (gn_partial_out) throw std::runtime_error("block transform: fused GroupNorm sums need whole blocks and a shared matrix");
+  DDPMIR_HIP_CHECK(hipGetLastError());
+}
+
+bool block_transform_gn_fusable(int H, int W, int C, int bs) { return C == 64 && (bs == 4 || bs == 8) && (H % bs) == 0 && (W % bs) == 0; }
+
+void launch_gn_from_partials(const double* partial, int splits, int B, double n_per_group, int C, int G, const float* gamma,
+                             const float* beta, float* scale, float* shift, hipStream_t stream) {
+  hipLaunchKernelGGL(gn_finalize, dim3(G, B), dim3(256), 0, stream, partial, splits, n_per_group, C, round_up(C, 4), G, gamma, beta,
+                     scale, shift, round_up(C, 4));
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

@@ -44,9 +44,12 @@ PACKED_MAGIC = b"DDPMIRW\x00"
 class _RestorationModel:
     ARCH = spec.ARCH_WEBP
 
-    def __init__(self, device=None, dtype: str = "f32", attn_levels: str = "all", use_graph: bool = False):
+    def __init__(self, device=None, dtype: str = "f32", attn_levels: str = "all", use_graph: bool = False,
+                 fp8_min_channels: int | None = None):
         """attn_levels: 'all' = self-attention in every block (the reference); 'bottleneck' = only the three
-        bottleneck blocks (what BASELINE.json's configs describe; no reference parity claim)."""
+        bottleneck blocks (what BASELINE.json's configs describe; no reference parity claim).
+        fp8_min_channels (dtype 'fp8'): 3x3 convs with at least this many input and output channels take e4m3 operands
+        (64, 128 or 256; None = the library's default)."""
         torch = _torch()
         self._lib = _lib.load()
         if device is None:
@@ -64,6 +67,8 @@ class _RestorationModel:
         self._loaded = False
         self._blob = None
         self.training = False
+        if fp8_min_channels is not None:
+            self.set_option("fp8_min_channels", fp8_min_channels)
 
     # ---- nn.Module look-alikes used by the reference call sites
     def to(self, device):

@@ -416,7 +416,9 @@ def test_conv_fp8_operand_layout_is_exact_on_integer_data(ops):
     product and partial sum is exact in fp32, so the result must EQUAL the fp32 convolution -- an asymmetric pattern that
     any wrong lane / k mapping, swizzle or tap order breaks.  3x3 and 1x1, ragged M, two K-chunk counts."""
     rng = np.random.default_rng(11)
-    for (b, h, w, cin, cout, k) in ((2, 8, 12, 256, 128, 3), (1, 5, 7, 320, 96, 3), (3, 16, 16, 512, 256, 1)):
+    # (Cout 64 = the two-column-tile instantiation of the full-resolution convs; 64 x 64 pixels: more than 256 tiles, BK = 32)
+    for (b, h, w, cin, cout, k) in ((2, 8, 12, 256, 128, 3), (1, 5, 7, 320, 96, 3), (3, 16, 16, 512, 256, 1), (2, 16, 24, 64, 64, 3),
+                                    (2, 12, 16, 128, 64, 3), (9, 64, 64, 64, 64, 3)):
         x = rng.integers(-4, 5, (b, h, w, cin)).astype(np.float32)
         wt = (rng.integers(-3, 4, (cout, cin, k, k)) * 0.125).astype(np.float32)
         wt[0, 0, 0, 0] = 0.375                                   # |w| max fixed -> the tensor scale is a known power of two
