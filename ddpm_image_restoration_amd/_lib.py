@@ -32,6 +32,7 @@ SYMBOLS = {
     "ddpmir_weight_layout_version": (C.c_int, []),
     "ddpmir_set_codec_library": (C.c_int, [C.c_int, C.c_char_p]),
     "ddpmir_host_codec_roundtrip_u8": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ddpmir_host_codec_threads": (C.c_int, []),
     "ddpmir_weight_blob_bytes": (C.c_size_t, [C.c_void_p]),
     "ddpmir_finalize_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ddpmir_param_count": (C.c_int64, [C.c_void_p]),

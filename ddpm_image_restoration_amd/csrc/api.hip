@@ -136,6 +136,8 @@ int ddpmir_host_codec_roundtrip_u8(int arch, const uint8_t* in, uint8_t* out, in
   }
 }
 
+int ddpmir_host_codec_threads(void) { return ddpmir::builtin_host_codec_threads(); }
+
 size_t ddpmir_weight_blob_bytes(ddpmir_ctx* ctx) {
   size_t n = 0;
   guarded(ctx, [&] { n = ctx->impl->weight_blob_bytes(); });

@@ -857,7 +857,6 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
       case 50: run_flash<32, 2, 8, 0, 1, 1, 4, 2, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
       case 51: run_flash<32, 2, 8, 0, 1, 1, 4, 2, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
       case 52: run_flash<32, 2, 8, 0, 1, 1, 4, 4, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
-      case 53: run_flash<32, 2, 8, 0, 1, 1, 4, 3, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
       case 54: run_flash<32, 2, 8, 0, 1, 1, 8, 2, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
       case 55: run_flash<32, 2, 8, 0, 1, 1, 2, 4, 1>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
       case 56: run_flash<32, 2, 8, 0, 1, 1, 2, 2, 0>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
@@ -885,8 +884,6 @@ void launch_attention_bf16(const float* qkv, float* out, int ldo, int B, int N, 
       case 16: run_flash<16, 2, 16, 0, 1, 0, 8>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;    // 4 WG/CU
       case 17: run_flash<16, 2, 16, 0, 1, 0, 6>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;    // 4 WG/CU, shorter stages
       case 18: run_flash<16, 2, 16>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;                // the general kernel alone
-      case 19: run_flash<16, 2, 16, 0, 1, 0, 8, 3>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;   // no-max, 3 query sub-tiles per wave
-      case 20: run_flash<16, 2, 16, 0, 1, 0, 12, 3>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
       case 21: run_flash<16, 2, 16, 0, 1, 0, 8, 4>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;   // 4 sub-tiles
       case 22: run_flash<16, 2, 16, 0, 1, 0, 10, 2>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;
       case 23: run_flash<16, 2, 16, 0, 1, 0, 4, 2>(qkv, out, ldo, B, N, C, heads, workspace, s, out16, opt); return;

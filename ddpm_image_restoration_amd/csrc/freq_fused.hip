@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
                                                             const __bf16* __restrict__ w2, const float* __restrict__ b2,
                                                             const float* __restrict__ boost, __bf16* __restrict__ S16, int H, int W,
                                                             int low, const __bf16* __restrict__ att16, const __bf16* __restrict__ wo,
-                                                            const float* __restrict__ bo, unsigned char* __restrict__ S8) {
+                                                            const float* __restrict__ bo, unsigned char* __restrict__ S8,
+                                                            const __bf16* __restrict__ xin16) {
   using G = FGeom<C>;
   constexpr int BB = BS * BS, NBLK = G::PT / BB, XS = G::XS, ROWB = G::ROWB, CPR = G::CPR, RSH = G::RSH, KS = G::KS, KK = G::KK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -89,7 +90,12 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = row0 + 4 * i + rsub;
-    xreg[i] = *reinterpret_cast<const float4*>(x + pix(row) * C + col0 + 4 * c4);
+    if (xin16) {   // x arrives as bf16 (the producing conv wrote no fp32 copy: half the bytes of this kernel's read)
+      const bf16x4 t = *reinterpret_cast<const bf16x4*>(xin16 + pix(row) * C + col0 + 4 * c4);
+      xreg[i] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+    } else {
+      xreg[i] = *reinterpret_cast<const float4*>(x + pix(row) * C + col0 + 4 * c4);
+    }
     *reinterpret_cast<float4*>(X32 + row * XS + col0 + 4 * c4) = xreg[i];
   }
   if (tid < BB) Ts[tid] = dct[tid];
@@ -310,7 +316,8 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
 
 template <int BS, int C, bool OP>
 void launch_t(const float* x, const float* dct, const void* w1, const float* b1, const void* w2, const float* b2, const float* boost,
-              void* S16, int B, int H, int W, int low, const void* att16, const void* wo, const float* bo, hipStream_t s, void* S8) {
+              void* S16, int B, int H, int W, int low, const void* att16, const void* wo, const float* bo, hipStream_t s, void* S8,
+              const void* xin16) {
   using G = FGeom<C>;
   constexpr int LDS = G::X32_BYTES + G::A16_BYTES + (BS * BS + C + 2 * C + (OP ? C : 0)) * 4;
   static PerDeviceOnce attr;
@@ -320,19 +327,21 @@ void launch_t(const float* x, const float* dct, const void* w1, const float* b1,
   const int64_t tiles = (int64_t)B * (H / BS) * (W / BS) / (G::PT / (BS * BS));
   hipLaunchKernelGGL((freq_gate_fused_k<BS, C, OP>), dim3((unsigned)tiles), dim3(256), LDS, s, x, dct, reinterpret_cast<const __bf16*>(w1), b1,
                      reinterpret_cast<const __bf16*>(w2), b2, boost, reinterpret_cast<__bf16*>(S16), H, W, low,
-                     reinterpret_cast<const __bf16*>(att16), reinterpret_cast<const __bf16*>(wo), bo, reinterpret_cast<unsigned char*>(S8));
+                     reinterpret_cast<const __bf16*>(att16), reinterpret_cast<const __bf16*>(wo), bo, reinterpret_cast<unsigned char*>(S8),
+                     reinterpret_cast<const __bf16*>(xin16));
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 
 template <bool OP>
 void launch_op(const float* x, const float* dct, const void* w1, const float* b1, const void* w2, const float* b2, const float* boost,
-               void* S16, int B, int H, int W, int C, int bs, int low, const void* att16, const void* wo, const float* bo, hipStream_t s, void* S8) {
+               void* S16, int B, int H, int W, int C, int bs, int low, const void* att16, const void* wo, const float* bo, hipStream_t s, void* S8,
+               const void* xin16) {
   if (C == 64) {
-    if (bs == 8) launch_t<8, 64, OP>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, att16, wo, bo, s, S8);
-    else launch_t<4, 64, OP>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, att16, wo, bo, s, S8);
+    if (bs == 8) launch_t<8, 64, OP>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, att16, wo, bo, s, S8, xin16);
+    else launch_t<4, 64, OP>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, att16, wo, bo, s, S8, xin16);
   } else {
-    if (bs == 8) launch_t<8, 128, OP>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, att16, wo, bo, s, S8);
-    else launch_t<4, 128, OP>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, att16, wo, bo, s, S8);
+    if (bs == 8) launch_t<8, 128, OP>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, att16, wo, bo, s, S8, xin16);
+    else launch_t<4, 128, OP>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, low, att16, wo, bo, s, S8, xin16);
   }
 }
 
@@ -347,14 +356,15 @@ bool freq_gate_fused_supported(int B, int H, int W, int C, int bs) {
 // att16 != nullptr: x is formed in the kernel as W_o att16 + b_o + x (the output projection of the block's attention)
 void launch_freq_gate_fused(const float* x, const float* dct, const void* w1, const float* b1, const void* w2, const float* b2,
                             const float* boost, void* S16, int B, int H, int W, int C, int bs, int low, hipStream_t s,
-                            const void* att16, const void* wo, const float* bo, void* S8) {
+                            const void* att16, const void* wo, const float* bo, void* S8, const void* xin16) {
   if (!S16 && !S8) throw std::runtime_error("fused frequency gates: no output");
+  if (!x && !xin16) throw std::runtime_error("fused frequency gates: no input");
   if (!freq_gate_fused_supported(B, H, W, C, bs)) throw std::runtime_error("fused frequency gates: unsupported shape");
   if (att16) {
     if (!wo || !bo) throw std::runtime_error("fused frequency gates: output projection needs its weight and bias");
-    launch_op<true>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, C, bs, low, att16, wo, bo, s, S8);
+    launch_op<true>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, C, bs, low, att16, wo, bo, s, S8, xin16);
   } else {
-    launch_op<false>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, C, bs, low, nullptr, nullptr, nullptr, s, S8);
+    launch_op<false>(x, dct, w1, b1, w2, b2, boost, S16, B, H, W, C, bs, low, nullptr, nullptr, nullptr, s, S8, xin16);
   }
 }
 

@@ -17,6 +17,7 @@
 // read applies the same XOR (rule: linear destination + permuted source + permuted read).  Rows outside the image (3x3 halo),
 // rows past M / Cout and channel chunks past Cin are fetched from a 16-byte zero page.
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -472,11 +473,22 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
 // fragments of tap dx at row offset dx; lanes whose pixel sits on the left / right image border get a zero fragment for
 // dx = -1 / +1 (the shifted row belongs to the neighbouring image row there).  A traffic drops 3x (B unchanged): 216 KiB ->
 // 122 KiB per tile at Cin = 64.  Same accumulation order as the generic kernel at BK = 32 (chunk outer, taps 0..8 inner).
-template <int NT>
+//
+// BUF = 1: the DMA loads go through raw buffer descriptors (buffer_load_dwordx4 ... lds).  The generic addressing spends ~16
+// VALU instructions per MFMA on 64-bit address arithmetic, bounds tests and the zero-page select of every load (PMC,
+// profiles/r03_gemm_pmc.txt: 74.9 M VALU instructions for 4.7 M MFMAs: the SIMD's vector issue, not the matrix pipe or the
+// memory system, was the busiest resource).  With descriptors a lane's byte offset for each kernel row is precomputed ONCE
+// (out-of-image rows and rows past M get an offset beyond num_records: the hardware writes zeros to LDS, no zero page), the
+// stage's channel / tap displacement is a wave-uniform SGPR soffset, and a load is issued without any vector arithmetic.
+// Needs Cin % 32 == 0 (no channel tail inside a stage) and operands below 2 GiB.
+constexpr unsigned BUF_OOB = 0x80000000u;     // voffset of a lane that must read zeros (+ soffset < 2^31 never wraps)
+
+template <int NT, bool BUF = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BK = 32, ROWB = 64, CPR = 4, RSH = 2, KS = 2, STAGES = 2;
-  constexpr int AR = BM + 8;                            // strip rows allocated (130 used): row r = pixel m0 - 1 + r
+  constexpr int AR = BUF ? BM + 16 : BM + 8;            // strip rows allocated (130 used): row r = pixel m0 - 1 + r
+                                                        // (BUF: 144, so that wave 0's whole third piece -- 16 rows -- lands inside the strip)
   constexpr int A_BYTES = AR * ROWB;
   constexpr int BROWS = 64;                             // weight rows per tap (>= NT * 32; 64 x 4 chunks = one slot per thread)
   constexpr int BT_BYTES = BROWS * ROWB, STAGE = A_BYTES + 3 * BT_BYTES;
@@ -522,9 +534,64 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p) {
   const int b_n = b_row < NT * 32 ? n0 + b_row : p.Cout;       // rows past the tile read the zero page
   const int b_chunk = (tid & 3) ^ ((b_row >> RSH) & (CPR - 1));
 
+  // BUF: per-lane byte offsets, one per kernel row (dy = -1, 0, +1), computed once
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  unsigned av0[AL], av1[AL], av2[AL], avb[AL], bv = BUF_OOB, bvb = BUF_OOB;
+  __amdgpu_buffer_rsrc_t rsA, rsB, rsAb, rsBb;
+  if constexpr (BUF) {
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(A16), 0, (int)((size_t)M * p.lda16 * 2), 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(W16), 0, (int)((size_t)9 * p.Cout * p.Cin * 2), 0x00020000);
+    rsAb = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.Cinb ? A16b : A16), 0, p.Cinb ? (int)((size_t)M * p.lda16b * 2) : 0, 0x00020000);
+    rsBb = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.Cinb ? W16b : W16), 0, p.Cinb ? (int)((size_t)p.Cout * p.Cinb * 2) : 0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+      const unsigned base = ((unsigned)a_m[j] * (unsigned)p.lda16 + 8u * a_chunk[j]) * 2u;
+      const unsigned rowb = (unsigned)p.W * (unsigned)p.lda16 * 2u;
+      av0[j] = (a_ok[j] && a_y[j] >= 1) ? base - rowb : BUF_OOB;
+      av1[j] = a_ok[j] ? base : BUF_OOB;
+      av2[j] = (a_ok[j] && a_y[j] + 1 < p.H) ? base + rowb : BUF_OOB;
+      avb[j] = a_ok[j] ? ((unsigned)a_m[j] * (unsigned)p.lda16b + 8u * a_chunk[j]) * 2u : BUF_OOB;
+    }
+    if (b_n < p.Cout) {
+      bv = ((unsigned)b_n * (unsigned)p.Cin + 8u * b_chunk) * 2u;
+      bvb = ((unsigned)b_n * (unsigned)p.Cinb + 8u * b_chunk) * 2u;
+    }
+  }
+
   auto issue = [&](int itl) {
     const int it = it0 + itl;
     const unsigned sb = lds0 + (itl % STAGES) * STAGE;
+    if constexpr (BUF) {
+      // (wave_s: the wave id as an SGPR, so the LDS base of every piece is scalar arithmetic.  Pieces 0 and 1 cover strip rows
+      //  0 .. 127; piece 2 covers rows 128 .. 143 and is wave 0's alone -- lanes past row 129 carry BUF_OOB and store zeros)
+      const unsigned sbw = sb + wave_s * 1024;
+      if (it >= nit_main) {   // second K segment (the block's 1x1 shortcut): centre position only; Cinb may end inside the stage
+        const int c0 = (it - nit_main) * BK;
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+          if (j == 2 && wave_s != 0) continue;
+          const unsigned v = (c0 + 8 * a_chunk[j] < p.Cinb) ? avb[j] : BUF_OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsAb, (lds_ptr_t)(size_t)(sbw + j * 4096), 16, v, (unsigned)(c0 * 2), 0, 0);
+        }
+        const unsigned vb = (c0 + 8 * b_chunk < p.Cinb) ? bvb : BUF_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBb, (lds_ptr_t)(size_t)(sbw + A_BYTES + BT_BYTES), 16, vb, (unsigned)(c0 * 2), 0, 0);
+        return;
+      }
+      const int ck = it / 3, dyi = it - ck * 3;
+      const unsigned soA = (unsigned)(ck * BK * 2);
+#pragma unroll
+      for (int j = 0; j < AL; ++j) {
+        if (j == 2 && wave_s != 0) continue;
+        const unsigned v = dyi == 0 ? av0[j] : (dyi == 1 ? av1[j] : av2[j]);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(size_t)(sbw + j * 4096), 16, v, soA, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const unsigned soB = (unsigned)((((dyi * 3 + j) * p.Cout) * p.Cin + ck * BK) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(size_t)(sbw + A_BYTES + j * BT_BYTES), 16, bv, soB, 0, 0);
+      }
+      return;
+    }
     if (it >= nit_main) {   // second K segment (the block's 1x1 shortcut): centre position only
       const int c0 = (it - nit_main) * BK;
 #pragma unroll
@@ -576,13 +643,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) zero8[j] = (__bf16)0.f;
 
-  if (nit > 0) issue(0);
-  for (int it = 0; it < nit; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (it + 1 < nit) issue(it + 1);
-    const unsigned char* st = smem + (it % STAGES) * STAGE;
-    const bool seg2 = it0 + it >= nit_main;
+  // only the waves whose 32 pixels touch the left or right image border need the zero fragments (2 of W / 32 waves per image row):
+  // everybody else runs the tap loop without the per-fragment selects
+  const bool wave_border = BUF ? (__any(!x_ok[0] || !x_ok[2]) != 0) : true;
+  auto taps = [&](const unsigned char* st, const bool seg2, auto masked) {
 #pragma unroll
     for (int dxi = 0; dxi < 3; ++dxi) {
       if (seg2 && dxi != 1) continue;
@@ -591,7 +655,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         af[ks] = *reinterpret_cast<const bf16x8*>(st + row * ROWB + (((2 * ks + lh) ^ a_key) << 4));
-        if (!seg2 && !x_ok[dxi]) af[ks] = zero8;
+        if (decltype(masked)::value && !seg2 && !x_ok[dxi]) af[ks] = zero8;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           bfr[ks][nt] = *reinterpret_cast<const bf16x8*>(st + A_BYTES + dxi * BT_BYTES + (nt * 32 + lr) * ROWB + (((2 * ks + lh) ^ b_key) << 4));
@@ -601,24 +665,269 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bfr[ks][nt], acc[nt], 0, 0, 0);
     }
+  };
+  if (nit > 0) issue(0);
+  for (int it = 0; it < nit; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 1 < nit) issue(it + 1);
+    const unsigned char* st = smem + (it % STAGES) * STAGE;
+    const bool seg2 = it0 + it >= nit_main;
+    if (wave_border) taps(st, seg2, std::true_type());
+    else taps(st, seg2, std::false_type());
   }
   gemm16_epilogue<NT>(p, acc, smem, m0, n0, M, HW, nsplit, sk);
 }
 
+// ------------------------------------------------------------------------------------------------ weights-stationary 64 -> 64
+// The 3x3 convs with 64 input and 64 output channels (conv2 / conv_out of the full-resolution blocks: at 512 x 512, B = 8 a
+// third of all GEMM time) spend their time WAITING: per 128-pixel tile the strip kernel runs 72 MFMAs per wave (1.1 us of matrix
+// pipe) inside 17.7 us, six stage round trips of ~2.9 us each, and 12 of the 20 KB every stage fetches are the same 74 KB of
+// weights, fetched again by each of 16 384 workgroups (PMC, profiles/r03_gemm_pmc.txt: 50 % of the wave cycles parked on
+// s_waitcnt / s_barrier, matrix pipe 19 % busy).  This kernel turns that around:
+//   * one PERSISTENT workgroup per CU walks a contiguous range of 256-pixel tiles (its own halo rows stay in its XCD's L2);
+//   * the whole weight tensor lives in LDS for the workgroup's lifetime (9 x 64 x 64 bf16 = 72 KiB, fetched once);
+//   * only the activation strips stream: one 258-row strip per (32-channel chunk, kernel row) = 16.5 KiB per stage, through
+//     a THREE-buffer ring with two stages in flight across the raw s_barrier (counted s_waitcnt vmcnt, descriptor-addressed
+//     buffer_load ... lds with precomputed per-lane offsets: no vector arithmetic per load) -- and the ring keeps running
+//     across tile boundaries, so a tile's first strips arrive while the previous tile is still in its MFMAs and epilogue;
+//   * a wave owns 64 pixels x 64 channels (2 x 2 MFMA tiles): 24 ds_read_b128 per 24 MFMAs.
+// Accumulation order = the strip kernel's (chunk outer, taps 0..8, k-steps), so the results are bit-identical to it.
+// Optional second K segment (the block's 1x1 shortcut) with up to 32 channels (down1: the 8-channel image operand).
+namespace ws {
+constexpr int TM = 256;                                 // pixels per tile
+constexpr int AROWS = 264;                              // strip rows per stage buffer: 258 used (pixel m0 - 1 .. m0 + 256)
+constexpr int A_STAGE = AROWS * 64;                     // 16 896 B
+constexpr int RS = 3;                                   // ring buffers (two stages in flight)
+constexpr int W_BYTES = 9 * 2 * 64 * 64;                // resident weights [tap][chunk][cout][32 cin]
+constexpr int W2_BYTES = 64 * 64;                       // second-segment weights [cout][<= 32 cin]
+constexpr int EPI_BYTES = 4 * 32 * (64 + 4) * 4;        // gemm16_epilogue's wave tiles
+constexpr int LDS_BYTES = W_BYTES + W2_BYTES + RS * A_STAGE + EPI_BYTES;
+constexpr int AP = 5;                                   // DMA pieces per thread per stage (the fifth: wave 0 only)
+}  // namespace ws
+
+__global__ __launch_bounds__(256, 1) void conv64_ws_kernel(const IGemm p, int ntiles) {
+  using namespace ws;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Wres = smem;
+  unsigned char* W2 = smem + W_BYTES;
+  unsigned char* ring = W2 + W2_BYTES;
+  unsigned char* epi = ring + RS * A_STAGE;
+  constexpr int ROWB = 64, CPR = 4, RSH = 2, KS = 2;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int M = p.B * p.H * p.W, HW = p.H * p.W;
+  const int t0 = (int)((long long)ntiles * blockIdx.x / gridDim.x), t1 = (int)((long long)ntiles * (blockIdx.x + 1) / gridDim.x);
+  if (t0 >= t1) return;
+  const int NS = 6 + (p.Cinb ? 1 : 0);                  // stages per tile
+  const __bf16* A16 = reinterpret_cast<const __bf16*>(p.A16);
+  const __bf16* W16 = reinterpret_cast<const __bf16*>(p.Wt16);
+  const __bf16* A16b = reinterpret_cast<const __bf16*>(p.A16b);
+  const __bf16* W16b = reinterpret_cast<const __bf16*>(p.Wt16b);
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(A16), 0, (int)((size_t)M * p.lda16 * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(W16), 0, 9 * 64 * 64 * 2, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsAb = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.Cinb ? A16b : A16), 0,
+                                                                  p.Cinb ? (int)((size_t)M * p.lda16b * 2) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsWb = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.Cinb ? W16b : W16), 0, p.Cinb ? 64 * p.Cinb * 2 : 0, 0x00020000);
+
+  // ---- resident weights: LDS piece q = ((tap * 2 + ck) * 64 + cout) * 4 + pos holds global chunk pos ^ key(cout)
+#pragma unroll
+  for (int i = 0; i < W_BYTES / 16 / 256; ++i) {
+    const int q = i * 256 + tid, pos = q & 3, cout = (q >> 2) & 63, tc = q >> 8, ck = tc & 1, tap = tc >> 1;
+    const int chunk = pos ^ ((cout >> RSH) & (CPR - 1));
+    const unsigned v = (unsigned)(((tap * 64 + cout) * 64 + ck * 32 + 8 * chunk) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(size_t)(lds0 + (i * 256 + wave_s * 64) * 16), 16, v, 0, 0, 0);
+  }
+  if (p.Cinb) {   // [cout][Cinb <= 32] -> 64-byte rows, chunks past Cinb are zeros
+    const int pos = tid & 3, cout = tid >> 2, chunk = pos ^ ((cout >> RSH) & (CPR - 1));
+    const unsigned v = 8 * chunk < p.Cinb ? (unsigned)((cout * p.Cinb + 8 * chunk) * 2) : BUF_OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsWb, (lds_ptr_t)(size_t)(lds0 + W_BYTES + wave_s * 1024), 16, v, 0, 0, 0);
+  }
+
+  // ---- issue side: per-lane offsets of the tile whose stages are being fetched (recomputed when the issue side enters a tile)
+  int a_chunk[AP];
+#pragma unroll
+  for (int j = 0; j < AP; ++j) a_chunk[j] = (tid & 3) ^ ((((j * 256 + tid) >> 2) >> RSH) & (CPR - 1));
+  unsigned av0[AP], av1[AP], av2[AP], avb[AP];
+  auto set_tile = [&](int tile) {
+    const int m0 = tile * TM;
+    const unsigned rowb = (unsigned)p.W * (unsigned)p.lda16 * 2u;
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+      const int row = (j * 256 + tid) >> 2, m = m0 - 1 + row;
+      const bool ok = row < TM + 2 && m >= 0 && m < M;
+      const int mm = ok ? m : 0;
+      const int b = mm / HW, y = (mm - b * HW) / p.W;
+      const unsigned base = ((unsigned)mm * (unsigned)p.lda16 + 8u * a_chunk[j]) * 2u;
+      av0[j] = (ok && y >= 1) ? base - rowb : BUF_OOB;
+      av1[j] = ok ? base : BUF_OOB;
+      av2[j] = (ok && y + 1 < p.H) ? base + rowb : BUF_OOB;
+      avb[j] = (ok && 8 * a_chunk[j] < p.Cinb) ? ((unsigned)mm * (unsigned)p.lda16b + 8u * a_chunk[j]) * 2u : BUF_OOB;
+    }
+  };
+  auto issue = [&](int stage, int buf) {                // stage 0..5: (chunk, kernel row); 6: the 1x1 second segment
+    const unsigned sbw = lds0 + W_BYTES + W2_BYTES + buf * A_STAGE + wave_s * 1024;
+    if (stage >= 6) {
+#pragma unroll
+      for (int j = 0; j < AP; ++j) {
+        if (j == AP - 1) {   // rows 256 .. 263: wave 0, lanes 0 .. 31 (the other half of the piece would land past the buffer)
+          if (wave_s == 0 && lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsAb, (lds_ptr_t)(size_t)(sbw + j * 4096), 16, avb[j], 0, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsAb, (lds_ptr_t)(size_t)(sbw + j * 4096), 16, avb[j], 0, 0, 0);
+        }
+      }
+      return;
+    }
+    const int ck = stage / 3, dyi = stage - ck * 3;
+    const unsigned so = (unsigned)(ck * 64);
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+      const unsigned v = dyi == 0 ? av0[j] : (dyi == 1 ? av1[j] : av2[j]);
+      if (j == AP - 1) {
+        if (wave_s == 0 && lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(size_t)(sbw + j * 4096), 16, v, so, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(size_t)(sbw + j * 4096), 16, v, so, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][nt][r] = 0.f;
+  const int b_key = (lr >> RSH) & (CPR - 1);
+  bf16x8 zero8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) zero8[j] = (__bf16)0.f;
+
+  // ---- prologue: the first two stages of the first tile are in flight before the loop
+  const int total = (t1 - t0) * NS;
+  int itile = t0, istage = 0;                           // issue side
+  set_tile(itile);
+  auto issue_next = [&](int g) {                        // global stage g -> ring buffer g % RS
+    issue(istage, g % RS);
+    if (++istage == NS) { istage = 0; ++itile; if (itile < t1) set_tile(itile); }
+  };
+  issue_next(0);
+  if (total > 1) issue_next(1);
+
+  int g = 0;
+  for (int tile = t0; tile < t1; ++tile) {
+    const int m0 = tile * TM;
+    bool xl[2], xr[2], border[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int px = (m0 + wave * 64 + rb * 32 + lr) % p.W;
+      xl[rb] = px > 0; xr[rb] = px + 1 < p.W;
+      border[rb] = __any(!xl[rb] || !xr[rb]) != 0;
+    }
+    for (int s = 0; s < NS; ++s, ++g) {
+      // stage g has landed once at most the pieces of ONE younger stage of this wave are outstanding (wave 0 issues 5, the
+      // others 4 per stage); the barrier extends that to every wave's pieces and retires all reads of the buffer refilled next
+      if (g + 1 < total) {
+        if (wave_s == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (g + 2 < total) issue_next(g + 2);
+      const unsigned char* st = ring + (g % RS) * A_STAGE;
+      const bool seg2 = s >= 6;
+      const int ck = s / 3, dyi = s - ck * 3;
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi) {
+        if (seg2 && dxi != 1) continue;
+        const unsigned char* wt = seg2 ? W2 : Wres + ((dyi * 3 + dxi) * 2 + ck) * (64 * ROWB);
+        bf16x8 af[2][KS], bfr[2][KS];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const int row = wave * 64 + rb * 32 + lr + dxi, a_key = (row >> RSH) & (CPR - 1);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            af[rb][ks] = *reinterpret_cast<const bf16x8*>(st + row * ROWB + (((2 * ks + lh) ^ a_key) << 4));
+            if (border[rb] && !seg2 && ((dxi == 0 && !xl[rb]) || (dxi == 2 && !xr[rb]))) af[rb][ks] = zero8;
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            bfr[nt][ks] = *reinterpret_cast<const bf16x8*>(wt + (nt * 32 + lr) * ROWB + (((2 * ks + lh) ^ b_key) << 4));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[rb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][ks], bfr[nt][ks], acc[rb][nt], 0, 0, 0);
+      }
+    }
+    // ---- epilogue of the tile: the shared fused epilogue, once per 32-row block of the wave (it indexes rows as m0 + wave * 32)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      gemm16_epilogue<2>(p, acc[rb], epi, m0 + wave * 32 + rb * 32, 0, M, HW, 1, 0);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][nt][r] = 0.f;
+    }
+  }
+}
+
+bool conv64_ws_supported(const IGemm& p) {
+  const int64_t M = (int64_t)p.B * p.H * p.W;
+  const size_t lim = size_t(1) << 31;
+  return p.taps == 9 && p.Cin == 64 && p.Cout == 64 && !p.f8 && !p.pk_q && !p.sel_C && p.lda16 >= 64 && (p.lda16 % 8) == 0 &&
+         (p.Cinb == 0 || (p.Cinb <= 32 && (p.Cinb % 8) == 0 && p.A16b && p.Wt16b && (p.lda16b % 8) == 0)) &&
+         (size_t)M * p.lda16 * 2 < lim && (!p.Cinb || (size_t)M * p.lda16b * 2 < lim) && M >= 2 * 256 * 256 &&
+         !exp_switch("DDPMIR_NO_WS64");
+}
+
+void launch_conv64_ws(const IGemm& p, int64_t M, hipStream_t stream) {
+  static PerDeviceOnce attr;
+  static int n_cu = 0;
+  attr.run([] {
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ws::LDS_BYTES));
+    int dev = 0;
+    hipDeviceProp_t prop;
+    DDPMIR_HIP_CHECK(hipGetDevice(&dev));
+    DDPMIR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount;
+  });
+  const int ntiles = (int)cdiv64(M, ws::TM);
+  const int grid = std::min(ntiles, n_cu > 0 ? n_cu : 256);
+  IGemm q = p;
+  q.nmajor = 0; q.tap_pack = 0;
+  hipLaunchKernelGGL(conv64_ws_kernel, dim3(grid), dim3(256), ws::LDS_BYTES, stream, q, ntiles);
+}
+
 template <int NT>
 void launch_strip(const IGemm& p, int64_t M, hipStream_t stream) {
-  constexpr int STAGE = (BM + 8) * 64 + 3 * 64 * 64;
+  constexpr int STAGE = (BM + 8) * 64 + 3 * 64 * 64, STAGE_B = (BM + 16) * 64 + 3 * 64 * 64;
   constexpr int HN = NT < 2 ? NT : 2;
   constexpr int EPI = 4 * 32 * (HN * 32 + 4) * 4;
-  constexpr int LDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+  constexpr int LDS = 2 * STAGE > EPI ? 2 * STAGE : EPI, LDS_B = 2 * STAGE_B > EPI ? 2 * STAGE_B : EPI;
   static PerDeviceOnce attr;
   attr.run([] {
-    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
   });
   const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
   IGemm q = p;
   q.nmajor = 0; q.tap_pack = 0;
-  hipLaunchKernelGGL((conv3x3_strip_kernel<NT>), dim3(gx, gy, 1), dim3(256), LDS, stream, q);
+  // descriptor-addressed loads: whole 32-channel stages and operands below 2 GiB (32-bit offsets with headroom for soffset)
+  const size_t lim = size_t(1) << 31;
+  const bool buf = (p.Cin % 32) == 0 && (size_t)M * p.lda16 * 2 < lim && (size_t)9 * p.Cout * p.Cin * 2 < lim &&
+                   (!p.Cinb || ((size_t)M * p.lda16b * 2 < lim && (p.Cinb % 8) == 0)) && !exp_switch("DDPMIR_NO_BUFLOAD");
+  if (buf) hipLaunchKernelGGL((conv3x3_strip_kernel<NT, true>), dim3(gx, gy, 1), dim3(256), LDS_B, stream, q);
+  else hipLaunchKernelGGL((conv3x3_strip_kernel<NT, false>), dim3(gx, gy, 1), dim3(256), LDS, stream, q);
 }
 
 // out[m][n] = epilogue(sum_s ws[s][m][n]) (s ascending): bias, time bias, activation, factors, residual; optional bf16 / e4m3 copy
@@ -659,7 +968,7 @@ __global__ void splitk_reduce_k(const IGemm p, int nsplit, int64_t M, int HW) {
 __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C, int Cs, const float* __restrict__ scale,
                              const float* __restrict__ shift, int act, __bf16* __restrict__ out, int ld16,
                              __bf16* __restrict__ raw, int ldraw, int64_t M, double* __restrict__ zero, int nzero,
-                             unsigned char* __restrict__ out8, int ld8) {
+                             unsigned char* __restrict__ out8, int ld8, const __bf16* __restrict__ x16in) {
   if (blockIdx.x == 0)
     for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0.0;
   const int C8 = (C + 7) / 8;
@@ -674,7 +983,12 @@ __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f), s = t, f = t;
       const bool ok = c + 4 * h < C;                     // C is a multiple of 4
       if (ok) {
-        t = *reinterpret_cast<const float4*>(x + m * ldx + c + 4 * h);
+        if (x16in) {
+          const bf16x4 tb = *reinterpret_cast<const bf16x4*>(x16in + m * ldx + c + 4 * h);
+          t = make_float4((float)tb[0], (float)tb[1], (float)tb[2], (float)tb[3]);
+        } else {
+          t = *reinterpret_cast<const float4*>(x + m * ldx + c + 4 * h);
+        }
         if (scale) {
           s = *reinterpret_cast<const float4*>(scale + (size_t)b * Cs + c + 4 * h);
           f = *reinterpret_cast<const float4*>(shift + (size_t)b * Cs + c + 4 * h);
@@ -758,6 +1072,9 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
   if constexpr (NT <= 2) {
     // full-resolution 3x3 convs with <= 64 output channels: one strip of pixel rows per kernel row serves its three taps
     if (p.taps == 9 && tiles >= 256 && p.Cin >= 32 && !(p.taps == 9 && p.Cin == 8) && !p.pk_q && !exp_switch("DDPMIR_NO_STRIP") && !GEMM_DBG(p)) {
+      if constexpr (NT == 2) {
+        if (conv64_ws_supported(p)) { launch_conv64_ws(p, M, stream); return; }   // 64 -> 64: persistent, weights resident in LDS
+      }
       launch_strip<NT>(p, M, stream);
       return;
     }
@@ -811,14 +1128,15 @@ void launch_gemm16(const IGemm& p, hipStream_t stream) {
 }
 
 void launch_gn_apply16(const float* x, int ldx, int B, int HW, int C, const float* scale, const float* shift, int act,
-                       void* out16, int ld16, void* raw16, int ldraw, hipStream_t s, double* zero, int nzero, void* out8, int ld8) {
+                       void* out16, int ld16, void* raw16, int ldraw, hipStream_t s, double* zero, int nzero, void* out8, int ld8,
+                       const void* x16in) {
   const int64_t M = (int64_t)B * HW;
   const int64_t total = M * ((C + 7) / 8);
   int64_t g = (total + 255) / 256;
   g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
   hipLaunchKernelGGL(gn_apply16_k, dim3((unsigned)g), dim3(256), 0, s, x, ldx, HW, C, round_up(C, 4), scale, shift, act,
                      reinterpret_cast<__bf16*>(out16), ld16, reinterpret_cast<__bf16*>(raw16), ldraw, M, zero, nzero,
-                     reinterpret_cast<unsigned char*>(out8), ld8);
+                     reinterpret_cast<unsigned char*>(out8), ld8, reinterpret_cast<const __bf16*>(x16in));
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

@@ -41,6 +41,20 @@ std::string g_path[3];                 // per DDPMIR_ARCH_*: library path given 
 std::string g_err;
 
 // ------------------------------------------------------------------------------------------------ thread pool
+// Threads of this process' pool: the CPUs it may run on, shared fairly between the ranks of one host -- torch.distributed.run
+// exports LOCAL_WORLD_SIZE, and with one rank per GPU every rank runs its own pool over the same cores: 8 ranks x 32 threads
+// on a 128-core host would oversubscribe the codec phase that the GPUs wait for.  DDPMIR_CODEC_THREADS overrides; cap 32
+// (a lane holds 8 images: more threads than images have nothing to do).
+int pool_threads() {
+  cpu_set_t set;
+  int n = (sched_getaffinity(0, sizeof set, &set) == 0) ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+  int ranks = 1;
+  if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+  n = std::max(1, n / ranks);
+  if (const char* e = getenv("DDPMIR_CODEC_THREADS")) n = atoi(e);
+  return std::max(1, std::min(n, 32));
+}
+
 class Pool {
  public:
   static Pool& get() { static Pool p; return p; }
@@ -62,10 +76,7 @@ class Pool {
 
  private:
   Pool() {
-    cpu_set_t set;
-    int n = (sched_getaffinity(0, sizeof set, &set) == 0) ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
-    if (const char* e = getenv("DDPMIR_CODEC_THREADS")) n = atoi(e);
-    n = std::max(1, std::min(n, 32));
+    const int n = pool_threads();
     for (int i = 1; i < n; ++i) threads_.emplace_back([this] { loop(); });
   }
   ~Pool() {
@@ -130,6 +141,14 @@ bool sym(void* h, const char* name, T& fn, std::string& err) {
   return fn != nullptr;
 }
 
+// per-thread staging buffers, grown once and reused for every image (no allocation inside the sampling loop)
+struct Scratch { std::vector<uint8_t> rgb, dec; };
+Scratch& scratch(size_t bytes) {
+  thread_local Scratch s;
+  if (s.rgb.size() < bytes) { s.rgb.resize(bytes); s.dec.resize(bytes); }
+  return s;
+}
+
 void planar_to_rgb(const uint8_t* chw, uint8_t* hwc, int n) {
   const uint8_t *r = chw, *g = chw + n, *b = chw + 2 * n;
   for (int i = 0; i < n; ++i) { hwc[3 * i] = r[i]; hwc[3 * i + 1] = g[i]; hwc[3 * i + 2] = b[i]; }
@@ -165,12 +184,13 @@ bool webp_init() {
 // webp_inference.py:518-523: quality = clamp(int(q), 0, 100); save(format="WEBP", quality) ; open ; RGB
 int webp_image(const uint8_t* in_chw, uint8_t* out_chw, int H, int W, int quality) {
   const int n = H * W;
-  std::vector<uint8_t> rgb((size_t)3 * n), dec((size_t)3 * n);
+  Scratch& sc = scratch((size_t)3 * n);
+  std::vector<uint8_t>&rgb = sc.rgb, &dec = sc.dec;
   planar_to_rgb(in_chw, rgb.data(), n);
   uint8_t* bits = nullptr;
   const size_t nb = g_webp.EncodeRGB(rgb.data(), W, H, 3 * W, (float)std::max(0, std::min(100, quality)), &bits);
   if (nb == 0 || !bits) return 1;
-  uint8_t* r = g_webp.DecodeRGBInto(bits, nb, dec.data(), dec.size(), 3 * W);
+  uint8_t* r = g_webp.DecodeRGBInto(bits, nb, dec.data(), (size_t)3 * n, 3 * W);
   g_webp.Free(bits);
   if (!r) return 2;
   rgb_to_planar(dec.data(), out_chw, n);
@@ -264,6 +284,8 @@ bool avif_init() {
     // capped at 64 for aom).  The bitstream depends on that number only through "more than one thread" and through
     // autoTiling's tile count min(threads, ceil(area / 512^2), 32) -- checked for 1..64 threads at 128..512 pixels --
     // so the per-image encoders get Pillow's number, and avif_image() trims it to what can change the result.
+    // (The count is NOT divided by LOCAL_WORLD_SIZE: it must stay Pillow's for the bitstream to be Pillow's.  What actually
+    //  runs inside libavif per image is the trimmed number -- 2 threads up to 512 x 512 -- times the pool's threads above.)
     cpu_set_t set;
     int n = (sched_getaffinity(0, sizeof set, &set) == 0) ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
     if (const char* e = getenv("DDPMIR_AVIF_MAX_THREADS")) n = atoi(e);
@@ -281,7 +303,8 @@ bool avif_init() {
 int avif_image(const uint8_t* in_chw, uint8_t* out_chw, int H, int W, int quality) {
   const Avif& a = g_avif;
   const int n = H * W;
-  std::vector<uint8_t> rgbbuf((size_t)3 * n);
+  Scratch& sc = scratch((size_t)3 * n);
+  std::vector<uint8_t>&rgbbuf = sc.rgb, &dec = sc.dec;
   planar_to_rgb(in_chw, rgbbuf.data(), n);
   int rc = 0;
   void *im = nullptr, *en = nullptr, *de = nullptr;
@@ -314,7 +337,6 @@ int avif_image(const uint8_t* in_chw, uint8_t* out_chw, int H, int W, int qualit
     if (a.DecoderSetIOMemory(de, bits.data, bits.size) != 0 || a.DecoderParse(de) != 0 || a.DecoderNextImage(de) != 0) { rc = 16; break; }
     const void* dim = reinterpret_cast<const void*>((uintptr_t)rd<uint64_t>(de, off::de_image));
     if (!dim || rd<uint32_t>(dim, off::im_width) != (uint32_t)W || rd<uint32_t>(dim, off::im_height) != (uint32_t)H) { rc = 17; break; }
-    std::vector<uint8_t> dec((size_t)3 * n);
     unsigned char rgb2[off::rgb_size];
     a.RGBImageSetDefaults(rgb2, dim);
     wr<uint32_t>(rgb2, off::rgb_depth, 8);
@@ -360,6 +382,8 @@ ddpmir_codec_fn builtin_host_codec(int arch) {
   g_err = "the JPEG family has a device codec; no host library is bound for it";
   return nullptr;
 }
+
+int builtin_host_codec_threads() { return pool_threads(); }
 
 std::string builtin_host_codec_error() {
   std::lock_guard<std::mutex> g(g_mu);

@@ -11,5 +11,7 @@ void set_codec_library(int arch, const std::string& path);
 // NULL when the codec library cannot be loaded or fails its self-check, with the reason in builtin_host_codec_error()
 ddpmir_codec_fn builtin_host_codec(int arch);
 std::string builtin_host_codec_error();
+// threads of this process' codec pool: CPUs this process may run on / LOCAL_WORLD_SIZE, at most 32 (DDPMIR_CODEC_THREADS overrides)
+int builtin_host_codec_threads();
 
 }  // namespace ddpmir

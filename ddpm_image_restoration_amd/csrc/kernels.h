@@ -82,9 +82,10 @@ void launch_gn_from_sums(const double* sums, int B, int HW, int C, int G, const 
                          float* shift, hipStream_t stream, int ldsc = 0, int zero_to = 0);
 // fp32 -> bf16 with GroupNorm affine + activation applied once for the consuming conv; optional raw bf16 copy
 // (zero/nzero: optionally clears a small fp64 accumulator, e.g. IGemm::gn_sums of the GEMM that consumes this operand)
+// x16in != null: the input is bf16 [M][ldx] there (x unused)
 void launch_gn_apply16(const float* x, int ldx, int B, int HW, int C, const float* scale, const float* shift, int act,
                        void* out16, int ld16, void* raw16, int ldraw, hipStream_t s, double* zero = nullptr, int nzero = 0,
-                       void* out8 = nullptr, int ld8 = 0);
+                       void* out8 = nullptr, int ld8 = 0, const void* x16in = nullptr);
 
 // ------------------------------------------------------------------------------------------------ attention
 // softmax(Q K^T / sqrt(d)) V per (batch, head); qkv is [B][N][3C] (q | k | v, heads contiguous in C),
@@ -146,7 +147,9 @@ bool freq_gate_fused_supported(int B, int H, int W, int C, int bs);
 // (att16 != null: x := W_o att16 + b_o + x is formed inside, i.e. the attention's out_proj + residual rides along)
 void launch_freq_gate_fused(const float* x, const float* dct, const void* w1, const float* b1, const void* w2, const float* b2,
                             const float* boost, void* S16, int B, int H, int W, int C, int bs, int low, hipStream_t s,
-                            const void* att16 = nullptr, const void* wo = nullptr, const float* bo = nullptr, void* S8 = nullptr);
+                            const void* att16 = nullptr, const void* wo = nullptr, const float* bo = nullptr, void* S8 = nullptr,
+                            const void* xin16 = nullptr);
+// (xin16 != null: x is read as bf16 [B*H*W][C] from there instead of fp32 from `x`)
 // (S8 != null: S is written as OCP e4m3 there instead of bf16 at S16 -- the operand of an fp8 conv_out)
 // gn_partial_out (mixed 64-channel output, whole blocks, shared matrix: block_transform_gn_fusable): GroupNorm(8) partial sums
 // of the output per (sample, block, group), [B][(H/bs)*(W/bs)][8][2] doubles, for launch_gn_from_partials

@@ -761,7 +761,11 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   launch_gn_apply16(in, ldin, B, HW, bw.cinp, p.sc1, p.sh1, ACT_NONE, c1_f8 ? nullptr : p.a16, cin8, bw.has_shortcut ? p.x16 : nullptr,
                     cin8, s, nullptr, 0, c1_f8 ? p.a8 : nullptr, bw.conv1.cin16);
   STAGE("norm1 apply");
+  // With the statistics taken from the fp32 accumulators, conv1's output is only ever read by the norm2-apply pass: it is
+  // written once as bf16 (half the bytes out and in again); the deep levels (split-K, statistics pass over the tensor) keep fp32
+  const bool ha16 = fuse_gn && !exp_switch("DDPMIR_HA_FP32");
   if (fuse_gn) { c1.gn_sums = p.gn_sums; c1.gn_groups = gn_groups(C); }
+  if (ha16) { c1.out = nullptr; c1.out16 = p.hid16; c1.ldo16 = C; }
   if (c1_f8) { c1.A16 = p.a8; c1.lda16 = bw.conv1.cin16; conv8(bw.conv1, c1, s); }
   else conv16(bw.conv1, c1, s);
   STAGE("conv1");
@@ -770,14 +774,17 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   else launch_gn_scale_shift(p.hA, C, B, HW, C, gn_groups(C), bw.n2g, bw.n2b, p.gn_partial, p.sc2, p.sh2, s);
   STAGE("norm2 statistics");
   launch_gn_apply16(p.hA, C, B, HW, C, p.sc2, p.sh2, ACT_GELU, c2_f8 ? nullptr : p.a16, C, nullptr, 0, s, nullptr, 0,
-                    c2_f8 ? p.a8 : nullptr, C);
+                    c2_f8 ? p.a8 : nullptr, C, ha16 ? p.hid16 : nullptr);
   STAGE("norm2 apply + GELU");
   const bool attn = bw.level >= cfg.attn_min_level;
   // 64- and 128-channel blocks of the DCT families: DCT, both gate layers and S = x + g * xd run as one pass over x
   const bool fuse_freq = cfg.arch != DDPMIR_ARCH_AVIF && !exp_switch("DDPMIR_SPLIT_GATES") && !exp_switch("DDPMIR_NO_FREQ_FUSE") &&
                          freq_gate_fused_supported(B, H, W, C, k.dct_block);   // (e4m3 conv_out: the kernel writes S as e4m3)
-  IGemm c2 = g; c2.A16 = p.a16; c2.lda16 = C; c2.out = p.hB; c2.ldo = C;
-  if (attn) { c2.out16 = p.hB16; c2.ldo16 = C; }
+  // conv2's output x: where the one-pass frequency kernel is its only fp32 reader (no attention, or the 64-channel blocks whose
+  // out_proj + residual is formed inside that kernel) x is written as bf16 alone and read back as bf16
+  const bool hb16_only = fuse_freq && (!attn || C == 64) && !exp_switch("DDPMIR_HB_FP32");
+  IGemm c2 = g; c2.A16 = p.a16; c2.lda16 = C; c2.out = hb16_only ? nullptr : p.hB; c2.ldo = C;
+  if (attn || hb16_only) { c2.out16 = p.hB16; c2.ldo16 = C; }
   if (c2_f8) { c2.A16 = p.a8; conv8(bw.conv2, c2, s); }
   else conv16(bw.conv2, c2, s);
   STAGE("conv2");
@@ -824,8 +831,9 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
                       co_f8 ? p.S8 : nullptr, C);
   } else if (fuse_freq) {
     // (freq_fused.hip; with attention in the block, x = out_proj(att) + x is formed there too)
-    launch_freq_gate_fused(p.hB, bw.dct, bw.fg1.w16, bw.fg1.b, bw.fg2.w16, bw.fg2.b, p.boost, co_f8 ? nullptr : p.S16, B, H, W, C, k.dct_block,
-                           k.low_size, s, attn && C == 64 ? p.att16 : nullptr, bw.out_proj.w16, bw.out_proj.b, co_f8 ? p.S8 : nullptr);
+    launch_freq_gate_fused(hb16_only ? nullptr : p.hB, bw.dct, bw.fg1.w16, bw.fg1.b, bw.fg2.w16, bw.fg2.b, p.boost, co_f8 ? nullptr : p.S16, B, H, W, C,
+                           k.dct_block, k.low_size, s, attn && C == 64 ? p.att16 : nullptr, bw.out_proj.w16, bw.out_proj.b,
+                           co_f8 ? p.S8 : nullptr, hb16_only ? p.hB16 : nullptr);
   } else if (!split_gates) {
     launch_block_transform(p.hB, C, p.xd, C, B, H, W, C, k.dct_block, bw.dct, 0, 0.f, 1.f, s, p.xdl16, nullptr, k.low_size);
     IGemm a = g; a.A16 = p.xdl16; a.lda16 = C; a.epi_act = ACT_LRELU; a.out16 = p.hid16; a.ldo16 = C;

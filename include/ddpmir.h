@@ -92,6 +92,9 @@ int ddpmir_set_codec_library(int arch, const char* path);
  * context): replaces webp_compress / avif_compress when degrading inputs (webp_inference.py:669). */
 int ddpmir_host_codec_roundtrip_u8(int arch, const uint8_t* in_u8_nchw_host, uint8_t* out_u8_nchw_host, int B, int H, int W,
                                    int quality);
+/* threads of this process' built-in codec pool: the CPUs it may run on divided by LOCAL_WORLD_SIZE (one rank per GPU: the
+ * ranks of a host share its cores), at most 32; $DDPMIR_CODEC_THREADS overrides */
+int ddpmir_host_codec_threads(void);
 
 typedef struct ddpmir_loop_opts {
   ddpmir_codec_fn codec;      /* NULL = the family's built-in codec (see above) */

@@ -87,9 +87,10 @@ def test_conv_bf16_dma_gate_select(ops, H, W, bs, low):
 
 @pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(2, 16, 16, 64, 128, 64), (1, 8, 8, 512, 1024, 512), (2, 32, 32, 64, 3, 64),
                                               (1, 4, 4, 1024, 512, 1024), (3, 5, 9, 40, 24, 36), (2, 128, 128, 64, 128, 64),
-                                              (1, 192, 176, 64, 8, 48)])
+                                              (1, 192, 176, 64, 8, 48), (2, 256, 256, 64, 3, 64), (3, 200, 232, 64, 24, 64)])
 def test_conv_bf16_dma_second_k_segment(ops, B, H, W, C1, C2, Cout):
-    """3x3 conv_out with the block's 1x1 shortcut conv folded in as a second K segment (incl. split-K shapes)."""
+    """3x3 conv_out with the block's 1x1 shortcut conv folded in as a second K segment (incl. split-K shapes; the last two:
+    the weights-stationary persistent kernel of the 64 -> 64 full-resolution convs, image operand and a ragged last tile)."""
     def bf(z):
         u = np.ascontiguousarray(z, dtype=np.float32).view(np.uint32)
         return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
@@ -376,11 +377,14 @@ def test_randn_moments_and_shard_independence(ops):
     (1, 12, 20, 64, 64, 3), (2, 16, 16, 128, 384, 1), (2, 16, 16, 64, 32, 1), (5, 7, 3, 36, 40, 3), (1, 6, 10, 68, 96, 1),
     (1, 4, 4, 1024, 1024, 3), (3, 2, 2, 200, 132, 3), (1, 1, 1, 16, 8, 3), (2, 32, 32, 3, 64, 3), (1, 9, 130, 72, 128, 3),
     (3, 5, 9, 3, 64, 3), (1, 1, 1, 3, 16, 3), (2, 16, 24, 8, 40, 3),
-    (2, 128, 128, 64, 64, 3), (1, 160, 224, 32, 40, 3), (4, 96, 96, 128, 64, 3), (3, 128, 96, 64, 16, 3), (1, 256, 130, 72, 64, 3)])
+    (2, 128, 128, 64, 64, 3), (1, 160, 224, 32, 40, 3), (4, 96, 96, 128, 64, 3), (3, 128, 96, 64, 16, 3), (1, 256, 130, 72, 64, 3),
+    (2, 256, 256, 64, 64, 3), (3, 200, 232, 64, 64, 3), (9, 128, 128, 64, 64, 3)])
 def test_conv_bf16_dma(ops, B, H, W, Cin, Cout, k):
     """LDS-DMA bf16 GEMM (gemm16.hip), including the split-K atomics path (deep, few output tiles), channel tails
     (Cin % 64 != 0, Cin = 3 padded to 8: the tap-packed K axis), ragged M and Cout tiles, the row-strip kernel of the large
-    3x3 convs with <= 64 output channels (tiles crossing image rows, channel tails), 1x1 maps whose every tap but the centre is halo."""
+    3x3 convs with <= 64 output channels (tiles crossing image rows, channel tails), 1x1 maps whose every tap but the centre is
+    halo, and (last three shapes, >= 131 072 pixels) the weights-stationary persistent kernel of the 64 -> 64 convs: tiles that
+    straddle two images, a ragged last tile, several tiles per workgroup."""
     def bf(z):
         u = np.ascontiguousarray(z, dtype=np.float32).view(np.uint32)
         return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)

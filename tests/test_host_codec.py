@@ -9,6 +9,8 @@ larger and odd-sized images.  Bit-exact is the bar: this is integer codec work.
 import ctypes as C
 import io
 
+import os
+
 import numpy as np
 import pytest
 
@@ -87,6 +89,25 @@ def test_bad_arguments_and_unknown_family_are_errors(lib):
     assert b"device codec" in lib.ddpmir_last_error(None)
     assert lib.ddpmir_host_codec_roundtrip_u8(spec.ARCH_WEBP, None, out.ctypes.data_as(C.c_void_p), 1, 32, 32, 10) < 0
     assert lib.ddpmir_set_codec_library(7, b"/nowhere.so") < 0
+
+
+def test_codec_pool_is_sized_per_rank_of_the_host():
+    """One rank per GPU: every rank owns a codec pool over the SAME host cores, so the pool takes cpus / LOCAL_WORLD_SIZE
+    threads (torch.distributed.run exports it), at most 32; DDPMIR_CODEC_THREADS overrides.  Read in a fresh process each."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); from ddpm_image_restoration_amd import _lib; "
+            "print(_lib.load().ddpmir_host_codec_threads())" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+    def threads(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("LOCAL_WORLD_SIZE", "DDPMIR_CODEC_THREADS")}
+        e.update(env)
+        return int(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.split()[-1])
+    cpus = len(os.sched_getaffinity(0))
+    assert threads() == max(1, min(cpus, 32))
+    assert threads(LOCAL_WORLD_SIZE="4") == max(1, min(cpus // 4, 32))
+    assert threads(LOCAL_WORLD_SIZE="1024") == 1
+    assert threads(LOCAL_WORLD_SIZE="8", DDPMIR_CODEC_THREADS="3") == 3
 
 
 def test_sanitizer_build_of_the_host_codec_pool(tmp_path):
