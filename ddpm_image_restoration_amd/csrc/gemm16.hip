@@ -680,6 +680,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p) {
 }
 
 // ------------------------------------------------------------------------------------------------ weights-stationary 64 -> 64
+// EXPERIMENT (round 3, -DDDPMIR_EXPERIMENTS builds only, DDPMIR_WS64=1): measured SLOWER than the strip kernel and not shipped.
+// 64 -> 64 at 512 x 512, B = 8: 511 us against 337 us.  Dissection with the dbg switches (tools/ws_dissect2.py,
+// profiles/r03_ws64_dissection.txt), per 256-pixel tile: 15.9 us = 8.4 us epilogue + ~2 us K loop (loads and MFMAs overlap:
+// either alone costs the same) + 5.4 us that remain with loads, MFMAs, barriers, address set-up AND epilogue all switched off.
+// With one 160-KiB workgroup per CU nothing overlaps the epilogue's 98 KiB of stores or any other serial phase, whereas the
+// strip kernel's three co-resident workgroups hide each other's; the design would need a second, epilogue-only wave group
+// fed through LDS, for which the resident weights leave no room.  Kept for the record of what was tried.
+#ifdef DDPMIR_EXPERIMENTS
 // The 3x3 convs with 64 input and 64 output channels (conv2 / conv_out of the full-resolution blocks: at 512 x 512, B = 8 a
 // third of all GEMM time) spend their time WAITING: per 128-pixel tile the strip kernel runs 72 MFMAs per wave (1.1 us of matrix
 // pipe) inside 17.7 us, six stage round trips of ~2.9 us each, and 12 of the 20 KB every stage fetches are the same 74 KB of
@@ -719,8 +727,15 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(const IGemm p, int nt
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const int lr = lane & 31, lh = lane >> 5;
   const int M = p.B * p.H * p.W, HW = p.H * p.W;
-  const int t0 = (int)((long long)ntiles * blockIdx.x / gridDim.x), t1 = (int)((long long)ntiles * (blockIdx.x + 1) / gridDim.x);
-  if (t0 >= t1) return;
+  // Tile walk: in round i the workgroups of the grid hold the G CONSECUTIVE tiles [i G, (i + 1) G) -- so at any moment the chip
+  // streams one contiguous 4 MiB stretch of the tensor, spread over every memory channel (contiguous per-workgroup ranges put
+  // all 256 CUs on addresses exactly 1 MiB apart, i.e. on the same channels: 556 us instead of 378 for the strip kernel) -- and
+  // within a round each XCD (workgroup id mod 8) owns a contiguous eighth, so vertically adjacent tiles share that XCD's L2.
+  const int G = gridDim.x;
+  const int slot = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t0 = slot;                                  // tiles t0, t0 + G, t0 + 2 G, ... < ntiles
+  if (t0 >= ntiles) return;
+  const int my_tiles = (ntiles - 1 - t0) / G + 1;
   const int NS = 6 + (p.Cinb ? 1 : 0);                  // stages per tile
   const __bf16* A16 = reinterpret_cast<const __bf16*>(p.A16);
   const __bf16* W16 = reinterpret_cast<const __bf16*>(p.Wt16);
@@ -769,6 +784,7 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(const IGemm p, int nt
     }
   };
   auto issue = [&](int stage, int buf) {                // stage 0..5: (chunk, kernel row); 6: the 1x1 second segment
+    if (GEMM_DBG(p) & 1) return;                        // (experiments build: dissection run without the activation loads)
     const unsigned sbw = lds0 + W_BYTES + W2_BYTES + buf * A_STAGE + wave_s * 1024;
     if (stage >= 6) {
 #pragma unroll
@@ -807,18 +823,19 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(const IGemm p, int nt
   for (int j = 0; j < 8; ++j) zero8[j] = (__bf16)0.f;
 
   // ---- prologue: the first two stages of the first tile are in flight before the loop
-  const int total = (t1 - t0) * NS;
-  int itile = t0, istage = 0;                           // issue side
-  set_tile(itile);
-  auto issue_next = [&](int g) {                        // global stage g -> ring buffer g % RS
-    issue(istage, g % RS);
-    if (++istage == NS) { istage = 0; ++itile; if (itile < t1) set_tile(itile); }
-  };
-  issue_next(0);
-  if (total > 1) issue_next(1);
+  const int total = my_tiles * NS;
+  int itile = t0, istage = 0;                           // issue side (plain locals updated in line: a lambda capturing them by
+  set_tile(itile);                                      //  reference put them -- and 30 scratch round trips per tile -- on the stack)
+#define WS_ISSUE_NEXT(gg)                                                                                   \
+  do {                                                                                                      \
+    issue(istage, (gg) % RS);                                                                               \
+    if (++istage == NS) { istage = 0; itile += G; if (itile < ntiles && !(GEMM_DBG(p) & 32)) set_tile(itile); } \
+  } while (0)
+  WS_ISSUE_NEXT(0);
+  if (total > 1) WS_ISSUE_NEXT(1);
 
   int g = 0;
-  for (int tile = t0; tile < t1; ++tile) {
+  for (int tile = t0; tile < ntiles; tile += G) {
     const int m0 = tile * TM;
     bool xl[2], xr[2], border[2];
 #pragma unroll
@@ -830,6 +847,7 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(const IGemm p, int nt
     for (int s = 0; s < NS; ++s, ++g) {
       // stage g has landed once at most the pieces of ONE younger stage of this wave are outstanding (wave 0 issues 5, the
       // others 4 per stage); the barrier extends that to every wave's pieces and retires all reads of the buffer refilled next
+      if (!(GEMM_DBG(p) & 64)) {
       if (g + 1 < total) {
         if (wave_s == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -837,10 +855,12 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(const IGemm p, int nt
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
-      if (g + 2 < total) issue_next(g + 2);
+      }
+      if (g + 2 < total) WS_ISSUE_NEXT(g + 2);
       const unsigned char* st = ring + (g % RS) * A_STAGE;
       const bool seg2 = s >= 6;
       const int ck = s / 3, dyi = s - ck * 3;
+      if (GEMM_DBG(p) & 4) continue;                    // (dissection run without fragment reads and MFMAs)
 #pragma unroll
       for (int dxi = 0; dxi < 3; ++dxi) {
         if (seg2 && dxi != 1) continue;
@@ -881,13 +901,15 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(const IGemm p, int nt
   }
 }
 
+#undef WS_ISSUE_NEXT
+
 bool conv64_ws_supported(const IGemm& p) {
   const int64_t M = (int64_t)p.B * p.H * p.W;
   const size_t lim = size_t(1) << 31;
   return p.taps == 9 && p.Cin == 64 && p.Cout == 64 && !p.f8 && !p.pk_q && !p.sel_C && p.lda16 >= 64 && (p.lda16 % 8) == 0 &&
          (p.Cinb == 0 || (p.Cinb <= 32 && (p.Cinb % 8) == 0 && p.A16b && p.Wt16b && (p.lda16b % 8) == 0)) &&
          (size_t)M * p.lda16 * 2 < lim && (!p.Cinb || (size_t)M * p.lda16b * 2 < lim) && M >= 2 * 256 * 256 &&
-         !exp_switch("DDPMIR_NO_WS64");
+         exp_switch("DDPMIR_WS64");
 }
 
 void launch_conv64_ws(const IGemm& p, int64_t M, hipStream_t stream) {
@@ -907,6 +929,7 @@ void launch_conv64_ws(const IGemm& p, int64_t M, hipStream_t stream) {
   q.nmajor = 0; q.tap_pack = 0;
   hipLaunchKernelGGL(conv64_ws_kernel, dim3(grid), dim3(256), ws::LDS_BYTES, stream, q, ntiles);
 }
+#endif  // DDPMIR_EXPERIMENTS
 
 template <int NT>
 void launch_strip(const IGemm& p, int64_t M, hipStream_t stream) {
@@ -1072,9 +1095,11 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
   if constexpr (NT <= 2) {
     // full-resolution 3x3 convs with <= 64 output channels: one strip of pixel rows per kernel row serves its three taps
     if (p.taps == 9 && tiles >= 256 && p.Cin >= 32 && !(p.taps == 9 && p.Cin == 8) && !p.pk_q && !exp_switch("DDPMIR_NO_STRIP") && !GEMM_DBG(p)) {
+#ifdef DDPMIR_EXPERIMENTS
       if constexpr (NT == 2) {
-        if (conv64_ws_supported(p)) { launch_conv64_ws(p, M, stream); return; }   // 64 -> 64: persistent, weights resident in LDS
+        if (conv64_ws_supported(p)) { launch_conv64_ws(p, M, stream); return; }   // (experiment: persistent, weights resident in LDS)
       }
+#endif
       launch_strip<NT>(p, M, stream);
       return;
     }

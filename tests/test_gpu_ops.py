@@ -90,7 +90,7 @@ def test_conv_bf16_dma_gate_select(ops, H, W, bs, low):
                                               (1, 192, 176, 64, 8, 48), (2, 256, 256, 64, 3, 64), (3, 200, 232, 64, 24, 64)])
 def test_conv_bf16_dma_second_k_segment(ops, B, H, W, C1, C2, Cout):
     """3x3 conv_out with the block's 1x1 shortcut conv folded in as a second K segment (incl. split-K shapes; the last two:
-    the weights-stationary persistent kernel of the 64 -> 64 full-resolution convs, image operand and a ragged last tile)."""
+    64 -> 64 at full-resolution sizes with the 3-channel image operand / a 24-channel operand and a ragged last tile)."""
     def bf(z):
         u = np.ascontiguousarray(z, dtype=np.float32).view(np.uint32)
         return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
@@ -383,8 +383,9 @@ def test_conv_bf16_dma(ops, B, H, W, Cin, Cout, k):
     """LDS-DMA bf16 GEMM (gemm16.hip), including the split-K atomics path (deep, few output tiles), channel tails
     (Cin % 64 != 0, Cin = 3 padded to 8: the tap-packed K axis), ragged M and Cout tiles, the row-strip kernel of the large
     3x3 convs with <= 64 output channels (tiles crossing image rows, channel tails), 1x1 maps whose every tap but the centre is
-    halo, and (last three shapes, >= 131 072 pixels) the weights-stationary persistent kernel of the 64 -> 64 convs: tiles that
-    straddle two images, a ragged last tile, several tiles per workgroup."""
+    halo, and (last three shapes, >= 131 072 pixels of 64 -> 64) the descriptor-addressed strip kernel at the sizes of the
+    full-resolution levels: tiles that straddle two images, a ragged last tile (also the shapes of the experiments build's
+    weights-stationary kernel)."""
     def bf(z):
         u = np.ascontiguousarray(z, dtype=np.float32).view(np.uint32)
         return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
