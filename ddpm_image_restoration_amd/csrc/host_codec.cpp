@@ -16,6 +16,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cmath>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -264,6 +265,40 @@ bool avif_layout_ok(std::string& err) {
   return ok;
 }
 
+int avif_image(const uint8_t* in_chw, uint8_t* out_chw, int H, int W, int quality);
+
+// Behaviour probe behind the offset table: the default-value check above cannot tell fields apart that share a default
+// (quality / qualityAlpha are both -1; pixels / rowBytes / the decoder's image all 0).  So before the codec is declared usable
+// one fixed 32 x 32 image goes through the very path the loop uses, at two qualities: the round trip must return the right
+// geometry, quality 95 must reproduce the image closely, quality 5 clearly worse -- which only happens when the quality
+// write, the RGB pixel / row-stride writes and the decoder's image pointer all land in the fields libavif reads.
+bool avif_behaviour_ok(std::string& err) {
+  const int H = 32, W = 32, n = H * W;
+  std::vector<uint8_t> in((size_t)3 * n), hi(in.size()), lo(in.size());
+  for (int c = 0; c < 3; ++c)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {   // a smooth pattern (measured with Pillow's libavif 1.4.1: mean abs error 4.4 at q95, 15.0 at q5)
+        const double v = 128.0 + 60.0 * std::sin((x * (1.0 + 0.3 * c) + 0.7 * y) / 3.0) + 40.0 * std::cos((x - y) / 5.0 + c);
+        in[(size_t)c * n + y * W + x] = (uint8_t)std::max(0.0, std::min(255.0, v));
+      }
+  const int r1 = avif_image(in.data(), hi.data(), H, W, 95), r2 = avif_image(in.data(), lo.data(), H, W, 5);
+  if (r1 != 0 || r2 != 0) { err += "behaviour probe: round trip failed (" + std::to_string(r1) + ", " + std::to_string(r2) + "); "; return false; }
+  double e_hi = 0.0, e_lo = 0.0;
+  for (size_t i = 0; i < in.size(); ++i) { e_hi += std::abs((int)hi[i] - (int)in[i]); e_lo += std::abs((int)lo[i] - (int)in[i]); }
+  e_hi /= in.size(); e_lo /= in.size();
+  if (!(e_hi < 8.0 && e_lo > 1.5 * e_hi + 1.0)) {
+    err += "behaviour probe: quality 95 / 5 gave mean abs errors " + std::to_string(e_hi) + " / " + std::to_string(e_lo) + " (struct fields not where expected); ";
+    return false;
+  }
+  return true;
+}
+
+bool avif_version_ok(std::string& err) {   // the offsets were verified against libavif 1.x (avif.h of 1.0 ... 1.4)
+  const char* v = g_avif.Version ? g_avif.Version() : nullptr;
+  if (!v || v[0] != '1' || v[1] != '.') { err += std::string("libavif version ") + (v ? v : "?") + " is outside the verified range 1.x; "; return false; }
+  return true;
+}
+
 bool avif_init() {
   std::lock_guard<std::mutex> g(g_mu);
   if (g_avif.tried) return g_avif.ok;
@@ -279,7 +314,7 @@ bool avif_init() {
       sym(h, "avifRWDataFree", a.RWDataFree, err) && sym(h, "avifDecoderCreate", a.DecoderCreate, err) &&
       sym(h, "avifDecoderDestroy", a.DecoderDestroy, err) && sym(h, "avifDecoderSetIOMemory", a.DecoderSetIOMemory, err) &&
       sym(h, "avifDecoderParse", a.DecoderParse, err) && sym(h, "avifDecoderNextImage", a.DecoderNextImage, err) &&
-      avif_layout_ok(err)) {
+      avif_version_ok(err) && avif_layout_ok(err)) {
     // Pillow hands the encoder max_threads = the CPUs this process may run on (AvifImagePlugin._get_default_max_threads,
     // capped at 64 for aom).  The bitstream depends on that number only through "more than one thread" and through
     // autoTiling's tile count min(threads, ceil(area / 512^2), 32) -- checked for 1..64 threads at 128..512 pixels --
@@ -290,7 +325,8 @@ bool avif_init() {
     int n = (sched_getaffinity(0, sizeof set, &set) == 0) ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
     if (const char* e = getenv("DDPMIR_AVIF_MAX_THREADS")) n = atoi(e);
     a.enc_threads = std::max(1, std::min(n, 64));
-    a.ok = true;
+    a.ok = avif_behaviour_ok(err);
+    if (!a.ok) g_err = "libavif: " + err;
   } else {
     g_err = "libavif: " + err;
   }
@@ -353,16 +389,27 @@ int avif_image(const uint8_t* in_chw, uint8_t* out_chw, int H, int W, int qualit
   return rc;
 }
 
+// failed != null: per-image status (0 = decoded image written); the batch then succeeds as a whole and the caller supplies the
+// failed images another way (the sampling loop: the reference's per-image JPEG fallback).  $DDPMIR_TEST_CODEC_FAIL=<i> makes
+// image i of every batch fail without calling the codec (test hook for that fallback).
 template <int (*ONE)(const uint8_t*, uint8_t*, int, int, int)>
-int batch_codec(void*, const uint8_t* in, uint8_t* out, int B, int H, int W, int quality) {
+int batch_codec_status(const uint8_t* in, uint8_t* out, int B, int H, int W, int quality, uint8_t* failed) {
   const size_t n = (size_t)3 * H * W;
   std::atomic<int> rc{0};
+  int inject = -1;
+  if (const char* e = getenv("DDPMIR_TEST_CODEC_FAIL")) inject = atoi(e);
   Pool::get().parallel_for(B, [&](int i) {
     int r = 1;
-    try { r = ONE(in + i * n, out + i * n, H, W, quality); } catch (...) { r = 99; }
+    if (i == inject) r = 98;
+    else { try { r = ONE(in + i * n, out + i * n, H, W, quality); } catch (...) { r = 99; } }
+    if (failed) failed[i] = r != 0;
     if (r != 0) rc.store(r);
   });
-  return rc.load();
+  return failed ? 0 : rc.load();
+}
+template <int (*ONE)(const uint8_t*, uint8_t*, int, int, int)>
+int batch_codec(void*, const uint8_t* in, uint8_t* out, int B, int H, int W, int quality) {
+  return batch_codec_status<ONE>(in, out, B, H, W, quality, nullptr);
 }
 
 }  // namespace
@@ -384,6 +431,12 @@ ddpmir_codec_fn builtin_host_codec(int arch) {
 }
 
 int builtin_host_codec_threads() { return pool_threads(); }
+
+int builtin_host_codec_status(int arch, const uint8_t* in, uint8_t* out, int B, int H, int W, int quality, uint8_t* failed) {
+  if (arch == DDPMIR_ARCH_WEBP && webp_init()) return batch_codec_status<webp_image>(in, out, B, H, W, quality, failed);
+  if (arch == DDPMIR_ARCH_AVIF && avif_init()) return batch_codec_status<avif_image>(in, out, B, H, W, quality, failed);
+  return -1;
+}
 
 std::string builtin_host_codec_error() {
   std::lock_guard<std::mutex> g(g_mu);

@@ -249,11 +249,13 @@ inline unsigned grid_for(int64_t total, int block) {
 size_t jpeg_sim_workspace(int B, int H, int W) { return (size_t)B * H * W * 3 + 1024; }
 
 // in/out: uint8 NCHW device pointers; scratch: jpeg_sim_workspace() bytes
+// force_sub: -1 = the JPEG family's rule (4:4:4 above q30, svd.ipynb c0:59); 1 = 4:2:0 whatever the quality -- Pillow's default
+// for a plain save(format="JPEG", quality=q), which is what the AVIF family's per-image fallback does (avif_inference.py:88-95)
 void launch_jpeg_roundtrip(const uint8_t* in, uint8_t* out, uint8_t* scratch, int B, int H, int W, int quality,
-                           hipStream_t s) {
+                           hipStream_t s, int force_sub) {
   if ((H % 16) != 0 || (W % 16) != 0) throw std::runtime_error("jpeg simulator: H and W must be multiples of 16");
   const int q = quality < 1 ? 1 : (quality > 100 ? 100 : quality);        // svd.ipynb c0:57
-  const int sub = q > 30 ? 0 : 1;                                        // svd.ipynb c0:59
+  const int sub = force_sub >= 0 ? force_sub : (q > 30 ? 0 : 1);         // svd.ipynb c0:59
   const int Hc = sub ? H / 2 : H, Wc = sub ? W / 2 : W;
   uint8_t* yp = scratch;
   uint8_t* cb = yp + (size_t)B * H * W;

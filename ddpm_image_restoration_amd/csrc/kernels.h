@@ -221,7 +221,7 @@ void launch_ddrm_update_p(const float* x_theta, const uint8_t* dec_u8, const flo
 // on-device JPEG encode->decode round trip, bit-exact to libjpeg-turbo/Pillow defaults (jpeg_sim.hip)
 size_t jpeg_sim_workspace(int B, int H, int W);
 void launch_jpeg_roundtrip(const uint8_t* in, uint8_t* out, uint8_t* scratch, int B, int H, int W, int quality,
-                           hipStream_t s);
+                           hipStream_t s, int force_sub = -1);   // force_sub = 1: 4:2:0 at every quality (Pillow's JPEG default)
 
 // phase_consistency (webp_inference.py:531-550) on NCHW planes via separable DFTs.
 struct DftPlan {           // device twiddle tables

@@ -1224,6 +1224,7 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
   ddpmir_codec_fn codec = opts->codec;
   void* codec_user = opts->codec_user;
   c.dev_codec = codec == nullptr && cfg.arch == DDPMIR_ARCH_JPEG;
+  const bool builtin_pool = !codec && !c.dev_codec;
   if (!codec && !c.dev_codec) {   // WebP / AVIF with no callback: the built-in host codec pool (libwebp / libavif C API)
     codec = builtin_host_codec(cfg.arch);
     codec_user = nullptr;
@@ -1272,16 +1273,39 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
     run_or_replay(p.g_front[l], graphs, s, [&] { step_front(l, nb, c, s); });
     if (!c.dev_codec) DDPMIR_HIP_CHECK(hipEventRecord(lane_ev_[l], s));
   };
+  std::vector<uint8_t> failed((size_t)nb, 0);
   auto codec_and_update = [&](int l, int i) {  // C(l, i) on the host, then U(l, i) on the stream
+    bool any_failed = false;
     if (!c.dev_codec) {
       DDPMIR_HIP_CHECK(hipEventSynchronize(lane_ev_[l]));
       const auto t0 = std::chrono::steady_clock::now();
-      int rc = codec(codec_user, pin_in_ + l * nh, pin_out_ + l * nh, nb, H, W, quality);
+      int rc;
+      if (builtin_pool) {   // per-image status: an image the codec cannot round-trip falls back to JPEG (below), as in the reference
+        rc = builtin_host_codec_status(cfg.arch, pin_in_ + l * nh, pin_out_ + l * nh, nb, H, W, quality, failed.data());
+        for (int j = 0; j < nb; ++j) any_failed = any_failed || failed[j];
+      } else {
+        rc = codec(codec_user, pin_in_ + l * nh, pin_out_ + l * nh, nb, H, W, quality);
+      }
       codec_host_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       codec_calls_ += 1;
       if (rc != 0) throw std::runtime_error("codec callback failed with code " + std::to_string(rc));
     }
     const bool with_phase = i > 0 && do_phase && (i % every) == 0;
+    if (any_failed && cfg.arch != DDPMIR_ARCH_AVIF)   // webp_compress has no fallback: the reference lets the exception propagate
+      throw std::runtime_error("codec: the built-in WebP codec failed on an image of the batch");
+    if (any_failed) {
+      // avif_inference.py:88-95: an image whose AVIF round trip raised is silently round-tripped as JPEG instead (Pillow's default
+      // 4:2:0, same quality).  The uint8 image is still on the device: the bit-exact JPEG simulator fills in its decoded pixels
+      // after the other images arrive from the host.  (Eager launches for this step: a captured timestep has no such branch.)
+      if ((H % 16) || (W % 16)) throw std::runtime_error("codec: per-image JPEG fallback needs image sides that are multiples of 16");
+      const size_t img = (size_t)3 * H * W;
+      DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_dec + l * nh, pin_out_ + l * nh, nh, hipMemcpyHostToDevice, s));
+      for (int j = 0; j < nb; ++j)
+        if (failed[j]) launch_jpeg_roundtrip(p.s_u8 + l * nh + j * img, p.s_dec + l * nh + j * img, p.s_jpeg, 1, H, W, quality, s, 1);
+      LoopConsts c2 = c;
+      c2.dev_codec = true;   // (step_back: the decoded images are already in s_dec)
+      step_back(l, nb, with_phase, c2, s);
+    } else
     run_or_replay(p.g_back[l][with_phase ? 1 : 0], graphs, s, [&] { step_back(l, nb, with_phase, c, s); });
     if (opts->trace) {
       float* tr = opts->trace + (size_t)(i_first - i) * 2 * n + l * nh;

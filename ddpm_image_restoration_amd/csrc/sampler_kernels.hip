@@ -439,7 +439,13 @@ void launch_ref_unit_phase_f64(const float* y, float* ure, float* uim, double* t
                                hipStream_t s) {
   const int64_t nrows = (int64_t)P * d.H;
   const size_t lds_r = (size_t)(DFT64_RB + 2) * d.W * sizeof(double), lds_c = (size_t)2 * d.H * sizeof(double);
-  if (lds_r > 64 * 1024 || lds_c > 64 * 1024) throw std::invalid_argument("phase_consistency: image too large for the fp64 reference-phase kernels");
+  // 160 KiB of LDS per workgroup: rows up to 3 413 pixels wide, columns up to 10 240 high (the fp32 transforms of the phase fix
+  // itself stop at 160 KiB too: dft_rows_lds).  Past the default 64 KiB the limit is raised per launch, as it depends on W / H.
+  if (lds_r > 160 * 1024 || lds_c > 160 * 1024) throw std::invalid_argument("phase_consistency: image too large for the fp64 reference-phase kernels (width <= 3413, height <= 10240)");
+  if (lds_r > 64 * 1024)
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dft_rows_f64_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+  if (lds_c > 64 * 1024)
+    DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dft_cols_unit_f64_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
   hipLaunchKernelGGL(dft_rows_f64_k, dim3((unsigned)cdiv64(nrows, DFT64_RB)), dim3(256), lds_r, s, y, tmp_re, tmp_im, d.W, nrows, d.cos_w,
                      d.sin_w);
   hipLaunchKernelGGL(dft_cols_unit_f64_k, dim3(cdiv(d.W, 64), cdiv(d.H, 4 * DFT64_UB), P), dim3(256), lds_c, s, (const double*)tmp_re,

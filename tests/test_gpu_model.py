@@ -304,6 +304,18 @@ def test_phase_consistency_golden(name, arch, golden, models):
     assert np.abs(out - g["pc_out"]).max() < 1e-5
 
 
+def test_phase_consistency_wide_image_past_the_default_lds_limit(models):
+    """The fp64 reference-phase kernels stage (4 + 2) * W doubles per workgroup: past W = 1365 that exceeds the default 64 KiB
+    of dynamic LDS and the launch limit is raised per call (up to 160 KiB: W <= 3413) instead of failing."""
+    from ddpm_image_restoration_amd.sampler import phase_consistency
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, (1, 3, 32, 1408)).astype(np.float32)
+    ref = rng.uniform(-1, 1, (1, 3, 32, 1408)).astype(np.float32)
+    got = phase_consistency(models(spec.ARCH_JPEG), tt(x), tt(ref), alpha=0.7).cpu().numpy()
+    want = O.phase_consistency(x, ref, 0.7)
+    assert np.abs(got - want).max() < 2e-4
+
+
 def test_forward_vs_oracle_128_bottleneck_attention(models, synth_state):
     """attn_levels='bottleneck' variant (BASELINE configs 2-5) at 128x128 against the oracle with the same switch."""
     x = synth.synth_images(1, 128, seed=77)
@@ -423,6 +435,45 @@ def test_builtin_host_codec_pool_equals_pillow_callback_in_the_loop(name, arch, 
         a = s.sample(y, q, steps=6, seed=3, host_codec="pillow")
         b = s.sample(y, q, steps=6, seed=3, host_codec="native")
         assert torch.equal(a, b), (name, q)
+
+
+def test_avif_per_image_jpeg_fallback_in_the_builtin_pool(models, monkeypatch):
+    """avif_inference.py:88-95: an image whose AVIF round trip raises is silently round-tripped as JPEG instead (Pillow's plain
+    save(format="JPEG", quality=q): 4:2:0 at every quality).  The built-in libavif pool keeps that behaviour per image: the
+    failed image's decoded pixels come from the device JPEG simulator, the rest from libavif.  $DDPMIR_TEST_CODEC_FAIL makes
+    image 1 of every lane batch fail; the expected result is the callback path with Pillow doing exactly what the reference
+    would have done for those images.  q50: the JPEG FAMILY's rule would pick 4:4:4 there -- the fallback must not."""
+    import io
+    import torch
+    from PIL import Image
+    from ddpm_image_restoration_amd import codec
+    from ddpm_image_restoration_amd.sampler import DDRMAVIFSampler
+    s = DDRMAVIFSampler(models(spec.ARCH_AVIF))
+
+    def reference_with_failure(src, quality, kind, out=None):
+        assert kind == "avif"
+        res = out if out is not None else np.empty_like(src)
+        for j in range(src.shape[0]):
+            if j == 1:   # "the AVIF encoder raised" -> the reference's except branch
+                buf = io.BytesIO()
+                Image.fromarray(np.ascontiguousarray(src[j].transpose(1, 2, 0))).save(buf, format="JPEG", quality=max(1, min(100, int(quality))))
+                buf.seek(0)
+                res[j] = np.asarray(Image.open(buf).convert("RGB"), dtype=np.uint8).transpose(2, 0, 1)
+            else:
+                res[j] = codec._one(src[j], quality, "avif")
+        return res
+
+    for q, size in ((50, 64), (10, 32)):
+        y = tt(O.compress(synth.synth_images(4, size, seed=80 + q), q, "avif"))
+        monkeypatch.setattr(codec, "roundtrip_u8", reference_with_failure)
+        want = s.sample(y, q, steps=4, seed=3, host_codec="pillow")
+        monkeypatch.undo()
+        clean = s.sample(y, q, steps=4, seed=3, host_codec="native")
+        monkeypatch.setenv("DDPMIR_TEST_CODEC_FAIL", "1")
+        got = s.sample(y, q, steps=4, seed=3, host_codec="native")
+        monkeypatch.delenv("DDPMIR_TEST_CODEC_FAIL")
+        assert torch.equal(got, want), (q, float((got - want).abs().max()))
+        assert not torch.equal(got[1], clean[1]) and torch.equal(got[0], clean[0])   # lanes of 2: images 1 and 3 took the fallback
 
 
 def test_half_precision_checkpoints_load_exactly(golden, synth_state):

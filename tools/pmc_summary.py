@@ -1,5 +1,7 @@
 """Per-kernel HBM-side traffic of the bench workload from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
-usage: pmc_summary.py <fetch_dir> <write_dir> <n_forwards> [--json FILE --key WORKLOAD_KEY --command "bench command"]
+usage: pmc_summary.py <fetch_dir> <write_dir> <n_forwards> [--json FILE --key WORKLOAD_KEY --command "bench command" --class gemm]
+(--class gemm: the roofline "kernel" is the GEMM class -- every gemm16_kernel / conv3x3_strip_kernel / splitk_reduce_k launch of
+one forward -- as bench.py reports for the workloads with attention at the bottleneck only)
 FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B); both counters are in KiB.  Durations are the dispatch
 timestamps of the same (profiled) runs.  With --json the bytes per launch of the roofline kernel (the level-0 attention
 dispatches: the flash kernel launches with the largest grid) are merged into FILE under WORKLOAD_KEY -- that is what
@@ -68,9 +70,21 @@ if "--json" in sys.argv:
     out = sys.argv[sys.argv.index("--json") + 1]
     key = sys.argv[sys.argv.index("--key") + 1]
     cmd = sys.argv[sys.argv.index("--command") + 1] if "--command" in sys.argv else None
-    f_kib, name, nl = roofline_kernel_bytes(sys.argv[1], "FETCH_SIZE")
-    w_kib, _, _ = roofline_kernel_bytes(sys.argv[2], "WRITE_SIZE")
+    if "--class" in sys.argv and sys.argv[sys.argv.index("--class") + 1] == "gemm":
+        sel = [k for k in fe if ("gemm16_kernel" in k or "conv3x3_strip" in k or "splitk_reduce" in k)]
+        f_kib = sum(fe[k][1] for k in sel) / n
+        w_kib = sum(wr.get(k, [0, 0.0, 0.0])[1] for k in sel) / n
+        name, nl = "GEMM class: " + ", ".join(sorted(set(k.split("<")[0] for k in sel))), int(sum(fe[k][0] for k in sel) / n)
+    else:
+        f_kib, name, nl = roofline_kernel_bytes(sys.argv[1], "FETCH_SIZE")
+        w_kib, _, _ = roofline_kernel_bytes(sys.argv[2], "WRITE_SIZE")
     doc = json.load(open(out)) if os.path.exists(out) else {"workloads": {}}
+    try:   # the source hash the measured library was built from (ddpmir_version()): bench.py marks the figure stale when it differs
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from ddpm_image_restoration_amd import build as _b
+        src_hash = _b.source_hash()
+    except Exception:
+        src_hash = None
     try:
         doc["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or doc.get("commit")
     except Exception:
@@ -80,6 +94,7 @@ if "--json" in sys.argv:
                                  "fetch_bytes_per_launch": 2 * f_kib * 1024, "write_bytes_per_launch": w_kib * 1024,
                                  "roofline_kernel_bytes_per_launch": 2 * f_kib * 1024 + w_kib * 1024,
                                  "all_kernels_read_GB_per_forward": tot[0], "all_kernels_write_GB_per_forward": tot[1],
-                                 "command": cmd, "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes"}
+                                 "command": cmd, "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes",
+                                 "src_hash": src_hash}
         json.dump(doc, open(out, "w"), indent=1)
         print(f"merged {key} into {out}: {doc['workloads'][key]['roofline_kernel_bytes_per_launch'] / 1e9:.3f} GB per level-0 launch")
