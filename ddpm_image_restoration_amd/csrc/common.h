@@ -52,6 +52,28 @@ __device__ __forceinline__ unsigned pack_e4m3x4(float4 v) {
   return (unsigned)r;
 }
 
+// Division of a non-negative 32-bit index by a launch-time constant (H*W, W): the compiler expands a runtime-divisor "/" into
+// ~40 vector instructions, and the GEMM kernels need several per thread in their prologue and per epilogue pass.  Round-up
+// magic number (Granlund-Montgomery / Hacker's Delight 10-9): q = (umulhi(n, m) + n) >> s evaluated without overflow; exact for
+// every n < 2^31.  Built on the host, carried in the kernel arguments.
+struct FastDiv {
+  unsigned d = 1, m = 0, s = 0;
+  FastDiv() = default;
+  explicit FastDiv(unsigned div) : d(div ? div : 1) {
+    s = 0;
+    while ((1ull << s) < d) ++s;                                  // s = ceil(log2 d)
+    m = (unsigned)(((1ull << 32) * ((1ull << s) - d)) / d + 1);   // < 2^32
+  }
+  __host__ __device__ __forceinline__ unsigned div(unsigned n) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned t = __umulhi(n, m);
+#else
+    const unsigned t = (unsigned)(((unsigned long long)n * m) >> 32);
+#endif
+    return s == 0 ? n : (t + ((n - t) >> 1)) >> (s - 1);
+  }
+};
+
 struct Status {
   int code = 0;
   std::string msg;

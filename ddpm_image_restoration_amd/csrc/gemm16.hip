@@ -87,7 +87,7 @@ __device__ __forceinline__ void gemm16_epilogue(const IGemm& p, f32x16 (&acc)[NT
         const int D = p.pk_D, nheads = p.pk_heads, C = nheads * D, NCH = D < 16 ? 1 : D >> 4, HPP = 64 / D, DPq = D < 16 ? 16 : D;
         const int mrow0 = m0 + wave * 32, nb = n0 + h * BNH;
         if (mrow0 >= M || nb >= 3 * C) continue;
-        const int b = mrow0 / HW, tile = (mrow0 - b * HW) >> 5;
+        const int b = (int)p.fd_hw.div((unsigned)mrow0), tile = (mrow0 - b * HW) >> 5;
         const int region = nb / C, head0 = (nb - region * C) / D;      // 0 = Q, 1 = K, 2 = V
         const int kt_bytes = NCH * 1024, rv = D <= 16 ? D + 1 : 32, tile_bytes = kt_bytes + 4 * rv * 16;
         if (region < 2) {
@@ -189,10 +189,12 @@ __device__ __forceinline__ void gemm16_epilogue(const IGemm& p, f32x16 (&acc)[NT
       float4 v = *reinterpret_cast<const float4*>(ct + row * BNP + 4 * c4);
       int b = 0, y = 0, x = 0;
       if (need_pos) {
-        b = m / HW;
-        const int rem = m - b * HW;
-        y = rem / p.W;
-        x = rem - y * p.W;
+        b = (int)p.fd_hw.div((unsigned)m);
+        if (p.epi_mask != MASK_NONE || p.sel_C) {       // only the frequency masks need the pixel's position inside its image
+          const int rem = m - b * HW;
+          y = (int)p.fd_w.div((unsigned)rem);
+          x = rem - y * p.W;
+        }
       }
       if (p.sel_C && is_low_freq(y, x, p.H, p.W, p.bs, p.low) == hi_cols) continue;   // the other gate owns this pixel
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
@@ -230,7 +232,7 @@ __device__ __forceinline__ void gemm16_epilogue(const IGemm& p, f32x16 (&acc)[NT
       for (int off = 1; off < span; off <<= 1) { gs1 += __shfl_xor(gs1, off); gs2 += __shfl_xor(gs2, off); }
       const int mw = m0 + wave * 32;
       if (rsub == 0 && (c4 % span) == 0 && mw < M) {
-        const int b = mw / HW, wt = (mw - b * HW) >> 5;
+        const int b = (int)p.fd_hw.div((unsigned)mw), wt = (mw - b * HW) >> 5;
         double* dst = p.gn_sums + (((size_t)b * (HW >> 5) + wt) * p.gn_groups + n / cpg) * 2;
         dst[0] = (double)gs1;
         dst[1] = (double)gs2;
@@ -309,8 +311,8 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
     const int m = m0 + row;
     const bool ok = m < M;
     const int mm = ok ? m : 0;
-    const int b = mm / HW, rem = mm - b * HW;
-    a_y[j] = rem / p.W; a_x[j] = rem - a_y[j] * p.W;
+    const int b = (int)p.fd_hw.div((unsigned)mm), rem = mm - b * HW;
+    a_y[j] = (int)p.fd_w.div((unsigned)rem); a_x[j] = rem - a_y[j] * p.W;
     a_ok[j] = ok;
     a_off[j] = (size_t)mm * p.lda16; a_m[j] = mm;
     a_chunk[j] = pos ^ ((row >> RSH) & (CPR - 1));     // which 8-channel chunk of the row this slot holds
@@ -524,8 +526,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p) {
     a_use[j] = row < BM + 2;
     a_ok[j] = a_use[j] && m >= 0 && m < M;
     const int mm = a_ok[j] ? m : 0;
-    const int b = mm / HW, rem = mm - b * HW;
-    a_y[j] = rem / p.W;
+    const int b = (int)p.fd_hw.div((unsigned)mm), rem = mm - b * HW;
+    a_y[j] = (int)p.fd_w.div((unsigned)rem);
     a_m[j] = mm;
     a_chunk[j] = pos ^ ((row >> RSH) & (CPR - 1));
   }
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p) {
 
   const int lr = lane & 31, lh = lane >> 5;
   const int arow = wave * 32 + lr;                      // the lane's pixel of the tile = strip row arow + 1
-  const int px = (m0 + arow) % p.W;                     // its column in the image: taps that leave the image row are zero
+  const int px = (m0 + arow) - (int)p.fd_w.div((unsigned)(m0 + arow)) * p.W;   // its column in the image (m % W == (m % HW) % W): taps that leave the image row are zero
   const bool x_ok[3] = {px > 0, true, px + 1 < p.W};
   const int b_key = (lr >> RSH) & (CPR - 1);
   bf16x8 zero8;
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(const IGemm p, int nt
       const int row = (j * 256 + tid) >> 2, m = m0 - 1 + row;
       const bool ok = row < TM + 2 && m >= 0 && m < M;
       const int mm = ok ? m : 0;
-      const int b = mm / HW, y = (mm - b * HW) / p.W;
+      const int b = (int)p.fd_hw.div((unsigned)mm), y = (int)p.fd_w.div((unsigned)(mm - b * HW));
       const unsigned base = ((unsigned)mm * (unsigned)p.lda16 + 8u * a_chunk[j]) * 2u;
       av0[j] = (ok && y >= 1) ? base - rowb : BUF_OOB;
       av1[j] = ok ? base : BUF_OOB;
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(const IGemm p, int nt
     bool xl[2], xr[2], border[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-      const int px = (m0 + wave * 64 + rb * 32 + lr) % p.W;
+      const int px = (m0 + wave * 64 + rb * 32 + lr) - (int)p.fd_w.div((unsigned)(m0 + wave * 64 + rb * 32 + lr)) * p.W;
       xl[rb] = px > 0; xr[rb] = px + 1 < p.W;
       border[rb] = __any(!xl[rb] || !xr[rb]) != 0;
     }
@@ -1146,9 +1148,13 @@ void launch_gemm16(const IGemm& p, hipStream_t stream) {
     throw std::runtime_error("gemm16: gate selection needs Cout = 2 * sel_C with sel_C a multiple of 64");
   const int64_t M = (int64_t)p.B * p.H * p.W;
   if (M <= 0 || p.Cout <= 0) return;
-  if (p.Cout <= 32) launch_bk<1>(p, M, stream);
-  else if (p.Cout <= 64) launch_bk<2>(p, M, stream);
-  else launch_bk<4>(p, M, stream);
+  if (M >= (int64_t(1) << 31)) throw std::runtime_error("gemm16: more than 2^31 pixels in one launch");
+  IGemm q = p;
+  q.fd_hw = FastDiv((unsigned)(p.H * p.W));
+  q.fd_w = FastDiv((unsigned)p.W);
+  if (q.Cout <= 32) launch_bk<1>(q, M, stream);
+  else if (q.Cout <= 64) launch_bk<2>(q, M, stream);
+  else launch_bk<4>(q, M, stream);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

@@ -65,6 +65,7 @@ struct IGemm {
   // undoes the per-tensor weight scale; out8 / ldo8: optional e4m3 copy of the epilogue result (operand of the next fp8 conv)
   int f8 = 0; float acc_scale = 1.f; void* out8 = nullptr; int ldo8 = 0;
   int nmajor = 0;   // set by the launcher: blockIdx.x is the N tile (weight-bound shapes), see gemm16.hip
+  FastDiv fd_hw, fd_w;   // set by launch_gemm16: exact division by H*W and by W (pixel index -> sample, row, column)
   int dbg = 0;   // timing experiments only: 1 skip A loads, 2 skip B loads, 4 skip MFMA, 8 skip stores, 16 skip LDS writes
 };
 void launch_igemm(const IGemm& p, hipStream_t stream);
