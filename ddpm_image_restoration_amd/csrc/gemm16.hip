@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
 constexpr unsigned BUF_OOB = 0x80000000u;     // voffset of a lane that must read zeros (+ soffset < 2^31 never wraps)
 
 template <int NT, bool BUF = false>
-__global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p) {
+__global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p, const int gx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BK = 32, ROWB = 64, CPR = 4, RSH = 2, KS = 2, STAGES = 2;
   constexpr int AR = BUF ? BM + 16 : BM + 8;            // strip rows allocated (130 used): row r = pixel m0 - 1 + r
@@ -499,8 +499,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = p.B * p.H * p.W, HW = p.H * p.W;
-  int bx = blockIdx.x, by = blockIdx.y;
-  if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);   // neighbouring tiles (shared halo rows) on one XCD
+  // gx = number of M tiles.  The grid may be smaller (launch_strip: three workgroups per CU): a workgroup then walks tiles
+  // blockIdx.x, blockIdx.x + gridDim.x, ... -- the ~16 000 workgroup launches of a full-resolution conv cost more than the
+  // tiles' own prologues (64 -> 64 at 512 x 512, B = 8: half of the launch's 377 us did not depend on K)
+  for (int tile = blockIdx.x; tile < gx; tile += gridDim.x) {
+  int bx = tile, by = blockIdx.y;
+  if ((gx & 7) == 0) bx = (bx & 7) * (gx >> 3) + (bx >> 3);   // neighbouring tiles (shared halo rows) on one XCD
   const int m0 = bx * BM, n0 = by * (NT * 32);
   const int nck = (p.Cin + BK - 1) / BK;
   const int nit_main = 3 * nck;
@@ -679,6 +683,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p) {
     else taps(st, seg2, std::false_type());
   }
   gemm16_epilogue<NT>(p, acc, smem, m0, n0, M, HW, nsplit, sk);
+  if (tile + (int)gridDim.x < gx) __syncthreads();   // the epilogue's wave tiles alias the stage ring the next tile refills
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ weights-stationary 64 -> 64
@@ -951,8 +957,21 @@ void launch_strip(const IGemm& p, int64_t M, hipStream_t stream) {
   const size_t lim = size_t(1) << 31;
   const bool buf = (p.Cin % 32) == 0 && (size_t)M * p.lda16 * 2 < lim && (size_t)9 * p.Cout * p.Cin * 2 < lim &&
                    (!p.Cinb || ((size_t)M * p.lda16b * 2 < lim && (p.Cinb % 8) == 0)) && !exp_switch("DDPMIR_NO_BUFLOAD");
-  if (buf) hipLaunchKernelGGL((conv3x3_strip_kernel<NT, true>), dim3(gx, gy, 1), dim3(256), LDS_B, stream, q);
-  else hipLaunchKernelGGL((conv3x3_strip_kernel<NT, false>), dim3(gx, gy, 1), dim3(256), LDS, stream, q);
+  // three workgroups share a CU (LDS); with more tiles than that the workgroups walk them (gridDim.x a multiple of 8 like gx,
+  // so a workgroup's tiles keep its XCD residue)
+  static int n_cu = 0;
+  static PerDeviceOnce cu_once;
+  cu_once.run([] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    DDPMIR_HIP_CHECK(hipGetDevice(&dev));
+    DDPMIR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount;
+  });
+  const int resident = 3 * (n_cu > 0 ? n_cu : 256) / gy;
+  const int grid_x = (gx > resident && !exp_switch("DDPMIR_NO_PERSIST")) ? std::max(8, resident & ~7) : gx;
+  if (buf) hipLaunchKernelGGL((conv3x3_strip_kernel<NT, true>), dim3(grid_x, gy, 1), dim3(256), LDS_B, stream, q, gx);
+  else hipLaunchKernelGGL((conv3x3_strip_kernel<NT, false>), dim3(grid_x, gy, 1), dim3(256), LDS, stream, q, gx);
 }
 
 // out[m][n] = epilogue(sum_s ws[s][m][n]) (s ascending): bias, time bias, activation, factors, residual; optional bf16 / e4m3 copy

@@ -1253,7 +1253,8 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
   // Host-codec families (WebP / AVIF, or JPEG through the callback): the batch is split into two micro-batch
   // lanes that are software-pipelined -- while the host runs the codec of lane A, the GPU runs the U-Net
   // forward of lane B, and lane A's next forward is enqueued before lane B's codec starts.  Images are
-  // independent, so the results are those of the unsplit batch.  The device JPEG codec needs no lanes.
+  // independent, so the results are those of the unsplit batch (bit for bit in fp32 mode; in bf16 / fp8 mode up to the
+  // mode's noise floor, because kernel selection follows the launch batch).  The device JPEG codec needs no lanes.
   const int nl = (!c.dev_codec && B >= 2 && (B % 2) == 0 && !exp_switch("DDPMIR_NO_OVERLAP")) ? 2 : 1;
   const int nb = B / nl;
   const size_t nh = (size_t)nb * 3 * H * W;                 // elements per lane

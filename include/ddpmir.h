@@ -102,7 +102,9 @@ typedef struct ddpmir_loop_opts {
   const float* noise;         /* optional device pointer [steps][B][3][H][W]: noise[i] is drawn at loop index i
                                  (replaces torch.randn_like, webp_inference.py:589); NULL = Philox(seed) */
   uint64_t seed;
-  uint64_t image_offset;      /* global index of image 0 of this shard (multi-GPU: results independent of N) */
+  uint64_t image_offset;      /* global index of image 0 of this shard (multi-GPU: the noise does not depend on the number of ranks;
+                                 fp32 mode is bit-identical for any sharding, bf16 / fp8 mode within its noise floor -- kernel
+                                 selection follows the per-rank batch) */
   float* trace;               /* optional device pointer [steps][2][B][3][H][W]: x_theta, x_t after each step */
   double noise_coeff;         /* <0 = the model family's default (0.2 / 0.15) */
   int phase_q;                /* <0 = default quality threshold of the phase fix (15 / 20 / 30) */
