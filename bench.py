@@ -47,22 +47,22 @@ STEP_GFLOP_AVIF = {("all", 32): 3.25, ("all", 64): 20.14, ("all", 256): 2604.5, 
                    ("bottleneck", 256): 156.7, ("bottleneck", 512): 627.2}
 
 
-def cpu_baseline(arch_name: str, size: int, quality: int, T: int, n_steps: int = 1):
+def cpu_baseline(arch_name: str, size: int, quality: int, T: int, n_steps: int = 1, batch: int = 1):
     """numpy oracle ("port") timed on this host's cores on a bounded sample of the same workload:
-    B=1 image, `n_steps` timesteps of the T-step schedule at the full image size."""
+    `batch` images (default 1), `n_steps` timesteps of the T-step schedule at the full image size."""
     import numpy as np
     from ddpm_image_restoration_amd import spec, synth
     from oracle import ddpm_oracle as O
     arch = spec.ARCH_NAMES[arch_name]
     sd = synth.synth_state_dict(arch)
     m = O.Model(arch, sd)
-    x0 = synth.synth_images(1, size, seed=123)
+    x0 = synth.synth_images(batch, size, seed=123)
     y = O.compress(x0, quality, arch_name)
     x_t = y.copy()
     pq, pevery, palpha = PHASE[arch_name]
     t0 = time.perf_counter()
     for i in range(T - 1, T - 1 - n_steps, -1):
-        t = (np.full((1,), i, dtype=np.float32) / np.float32(T)).astype(np.float32)
+        t = (np.full((batch,), i, dtype=np.float32) / np.float32(T)).astype(np.float32)
         th = m(x_t, t, t)
         dec = O.compress(th, quality, arch_name)
         xp = (th - dec) + y
@@ -72,8 +72,8 @@ def cpu_baseline(arch_name: str, size: int, quality: int, T: int, n_steps: int =
             x_t = O.phase_consistency(x_t, y, palpha)
     dt = (time.perf_counter() - t0) / n_steps
     threads = O.oracle_threads()    # the oracle's attention fans out over this many threads (BLAS single-threaded inside)
-    return {"value": 1.0 / (dt * T), "unit": "images/sec", "cores": int(threads), "kind": "port",
-            "sample": f"numpy oracle, {arch_name} U-Net, B=1 {size}x{size}, {n_steps} of {T} timesteps, {dt:.2f} s/step"}
+    return {"value": batch / (dt * T), "unit": "images/sec", "cores": int(threads), "kind": "port",
+            "sample": f"numpy oracle, {arch_name} U-Net, B={batch} {size}x{size}, {n_steps} of {T} timesteps, {dt:.2f} s/step"}
 
 
 def committed_traffic(key: str, lib_src_hash: str | None = None):
@@ -239,6 +239,19 @@ def run_workload(w: dict, env, dev, K: int, W: int, full: bool = False, graph: i
     if w.get("reference_it_per_s"):
         summary["reference_it_per_s"] = w["reference_it_per_s"]
         summary["reference_source"] = w.get("reference_source")
+    if w.get("reference_cpu_images_per_sec"):
+        summary["reference_cpu_images_per_sec"] = w["reference_cpu_images_per_sec"]
+        summary["reference_source"] = w.get("reference_source")
+    if w.get("cpu_sample_steps") and env.world == 1:   # the oracle on this host's cores, on a bounded sample of THIS workload
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-steps", "--size", str(R), "--quality", str(q),
+                                "--arch", arch_name, "--T", str(T), "--batch", str(B), "--steps", str(w["cpu_sample_steps"])],
+                               capture_output=True, text=True, timeout=300)
+            out = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            summary["cpu_baseline"] = json.loads(out[-1]) if (r.returncode == 0 and out) else {"value": None, "sample": "failed: " + r.stderr.strip()[-200:]}
+        except Exception as e:
+            summary["cpu_baseline"] = {"value": None, "sample": "not measured: %r" % (e,)}
     if w.get("note"):
         summary["note"] = w["note"]
     det.update(roof=roof, codec=codec_obj, gemm=gemm, routing=summary["attention_routing"])
@@ -260,7 +273,9 @@ EXTRA_WORKLOADS = [
               "restored PSNR -0.03 dB vs fp32 mode, forward error 2.1e-2 mean: profiles/r03_fp8_eval_configs4.txt)",
          arch="jpeg", size=512, batch=8, T=1000, quality=20, attn="bottleneck", dtype="fp8", steps=10, warmup=3, fp8_min_channels=64),
     dict(name="BASELINE configs[0] on the GPU: JPEG 32x32, B=4, T=50, q10, complete restoration (fp32 parity mode)",
-         arch="jpeg", size=32, batch=4, T=50, quality=10, attn="all", dtype="f32", steps=45, warmup=5),
+         arch="jpeg", size=32, batch=4, T=50, quality=10, attn="all", dtype="f32", steps=45, warmup=5, cpu_sample_steps=5,
+         reference_cpu_images_per_sec=0.364,
+         reference_source="the reference's own PyTorch CPU path on this configuration: 10.98 s for the batch, 8 threads, survey container (BASELINE.md section 2)"),
     dict(name="BASELINE configs[0] on the GPU, bf16 mode",
          arch="jpeg", size=32, batch=4, T=50, quality=10, attn="all", dtype="bf16", steps=45, warmup=5),
     dict(name="reference notebook shape: JPEG 64x64, B=18, 80 steps (svd imagenet.ipynb c0 output: 18.2 it/s on the author's CUDA GPU)",
@@ -300,10 +315,12 @@ def main():
     ap.add_argument("--workloads", default=None, help="comma-separated indices into the extra workload list (default: all)")
     ap.add_argument("--full", action="store_true", help="time one complete T-step restoration instead of a slice")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-steps", action="store_true", help=argparse.SUPPRESS)   # child: honour --steps / --batch for the oracle sample
     args = ap.parse_args()
     T = args.T
     if args.cpu_baseline_only:      # child process of the N=1 run: numpy oracle only, never touches the GPU
-        print(json.dumps(cpu_baseline(args.arch, args.size, args.quality, T)), flush=True)
+        print(json.dumps(cpu_baseline(args.arch, args.size, args.quality, T, n_steps=max(1, args.steps if args.cpu_steps else 1),
+                                      batch=args.batch if args.cpu_steps else 1)), flush=True)
         return
 
     import torch

@@ -1012,16 +1012,34 @@ __global__ void splitk_reduce_k(const IGemm p, int nsplit, int64_t M, int HW) {
 __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C, int Cs, const float* __restrict__ scale,
                              const float* __restrict__ shift, int act, __bf16* __restrict__ out, int ld16,
                              __bf16* __restrict__ raw, int ldraw, int64_t M, double* __restrict__ zero, int nzero,
-                             unsigned char* __restrict__ out8, int ld8, const __bf16* __restrict__ x16in) {
+                             unsigned char* __restrict__ out8, int ld8, const __bf16* __restrict__ x16in, FastDiv fd_c8, FastDiv fd_hw) {
   if (blockIdx.x == 0)
     for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0.0;
   const int C8 = (C + 7) / 8;
   const int64_t total = M * C8;
+  const bool small = total < (int64_t(1) << 31);        // 32-bit indices with exact magic-number division (the usual case)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / C8;
+    const int64_t m = small ? (int64_t)fd_c8.div((unsigned)i) : i / C8;
     const int c = (int)(i - m * C8) * 8;
-    const int b = (int)(m / HW);
+    const int b = small ? (int)fd_hw.div((unsigned)m) : (int)(m / HW);
     float v[8], r[8];
+    if (x16in && c + 8 <= C) {                          // bf16 input: one 16-byte load per thread
+      const bf16x8 tb = *reinterpret_cast<const bf16x8*>(x16in + m * ldx + c);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float4 s = make_float4(1.f, 1.f, 1.f, 1.f), f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) {
+          s = *reinterpret_cast<const float4*>(scale + (size_t)b * Cs + c + 4 * h);
+          f = *reinterpret_cast<const float4*>(shift + (size_t)b * Cs + c + 4 * h);
+        }
+        const float t0 = (float)tb[4 * h], t1 = (float)tb[4 * h + 1], t2 = (float)tb[4 * h + 2], t3 = (float)tb[4 * h + 3];
+        r[4 * h] = t0; r[4 * h + 1] = t1; r[4 * h + 2] = t2; r[4 * h + 3] = t3;
+        v[4 * h] = act_apply(fmaf(t0, s.x, f.x), act);
+        v[4 * h + 1] = act_apply(fmaf(t1, s.y, f.y), act);
+        v[4 * h + 2] = act_apply(fmaf(t2, s.z, f.z), act);
+        v[4 * h + 3] = act_apply(fmaf(t3, s.w, f.w), act);
+      }
+    } else {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f), s = t, f = t;
@@ -1045,6 +1063,7 @@ __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C
       v[4 * h + 1] = ok ? act_apply(fmaf(t.y, s.y, f.y), act) : 0.f;
       v[4 * h + 2] = ok ? act_apply(fmaf(t.z, s.z, f.z), act) : 0.f;
       v[4 * h + 3] = ok ? act_apply(fmaf(t.w, s.w, f.w), act) : 0.f;
+    }
     }
     bf16x8 o, q;
 #pragma unroll
@@ -1186,7 +1205,8 @@ void launch_gn_apply16(const float* x, int ldx, int B, int HW, int C, const floa
   g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
   hipLaunchKernelGGL(gn_apply16_k, dim3((unsigned)g), dim3(256), 0, s, x, ldx, HW, C, round_up(C, 4), scale, shift, act,
                      reinterpret_cast<__bf16*>(out16), ld16, reinterpret_cast<__bf16*>(raw16), ldraw, M, zero, nzero,
-                     reinterpret_cast<unsigned char*>(out8), ld8, reinterpret_cast<const __bf16*>(x16in));
+                     reinterpret_cast<unsigned char*>(out8), ld8, reinterpret_cast<const __bf16*>(x16in), FastDiv((unsigned)((C + 7) / 8)),
+                     FastDiv((unsigned)HW));
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

@@ -372,7 +372,10 @@ def test_randn_moments_and_shard_independence(ops):
     assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
     assert abs(float((a ** 4).mean()) - 3) < 0.05
     b = ops.randn(1 << 19, seed=7, offset=(1 << 19) // 4)
-    assert np.array_equal(a[1 << 19:], b)       # second half drawn as its own shard: same numbers@pytest.mark.gpu
+    assert np.array_equal(a[1 << 19:], b)       # second half drawn as its own shard: same numbers
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k", [
     (1, 12, 20, 64, 64, 3), (2, 16, 16, 128, 384, 1), (2, 16, 16, 64, 32, 1), (5, 7, 3, 36, 40, 3), (1, 6, 10, 68, 96, 1),
     (1, 4, 4, 1024, 1024, 3), (3, 2, 2, 200, 132, 3), (1, 1, 1, 16, 8, 3), (2, 32, 32, 3, 64, 3), (1, 9, 130, 72, 128, 3),
