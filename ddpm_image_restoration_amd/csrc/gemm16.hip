@@ -208,6 +208,10 @@ __device__ __forceinline__ void gemm16_epilogue(const IGemm& p, f32x16 (&acc)[NT
         if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + no); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      else if (p.res16) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.res16) + (size_t)m * p.ldres + no);
+        v.x += (float)t[0]; v.y += (float)t[1]; v.z += (float)t[2]; v.w += (float)t[3];
+      }
       if (p.gn_sums) {
         gs1 += (v.x + v.y) + (v.z + v.w);
         gs2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
@@ -997,6 +1001,10 @@ __global__ void splitk_reduce_k(const IGemm p, int nsplit, int64_t M, int HW) {
     if (p.mul) { const float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + n); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
     if (p.rowscale) { const float rs = p.rowscale[m / HW]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
     if (p.res) { const float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    else if (p.res16) {
+      const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.res16) + (size_t)m * p.ldres + n);
+      v.x += (float)t[0]; v.y += (float)t[1]; v.z += (float)t[2]; v.w += (float)t[3];
+    }
     if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + n) = v;
     if (out16) {
       bf16x4 o;
@@ -1007,8 +1015,22 @@ __global__ void splitk_reduce_k(const IGemm p, int nsplit, int64_t M, int HW) {
   }
 }
 
+// GELU for a result that is rounded to bf16: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, three orders below the bf16
+// rounding step) -- one v_rcp_f32, one v_exp_f32 and seven FMAs instead of ocml's erff (~45 instructions).  The norm2-apply pass
+// over a full-resolution tensor was bound by exactly that arithmetic (134 M elements: 156 us for 537 MB, 3.4 TB/s).
+__device__ __forceinline__ float gelu_bf16_grade(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float e = 1.0f - poly * __expf(-x * x);
+  return 0.5f * v * (1.0f + copysignf(e, v));
+}
+__device__ __forceinline__ float act16(float v, int act) { return act == ACT_GELU ? gelu_bf16_grade(v) : act_apply(v, act); }
+
 // fp32 [M][ldx] -> bf16 [M][ld16] with the GroupNorm affine + activation of the consuming conv applied once
 // (x*scale[b][c] + shift[b][c], then act); optionally also a raw bf16 copy (input of the 1x1 shortcut conv).
+// Large tensors (every thread has work in every sample): a thread keeps its 8-channel slot, walks sample by sample with its
+// scale / shift in registers (instead of four 16-byte loads per 16 bytes of payload) and has two pixels in flight.
 __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C, int Cs, const float* __restrict__ scale,
                              const float* __restrict__ shift, int act, __bf16* __restrict__ out, int ld16,
                              __bf16* __restrict__ raw, int ldraw, int64_t M, double* __restrict__ zero, int nzero,
@@ -1017,53 +1039,39 @@ __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C
     for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0.0;
   const int C8 = (C + 7) / 8;
   const int64_t total = M * C8;
-  const bool small = total < (int64_t(1) << 31);        // 32-bit indices with exact magic-number division (the usual case)
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = small ? (int64_t)fd_c8.div((unsigned)i) : i / C8;
-    const int c = (int)(i - m * C8) * 8;
-    const int b = small ? (int)fd_hw.div((unsigned)m) : (int)(m / HW);
-    float v[8], r[8];
-    if (x16in && c + 8 <= C) {                          // bf16 input: one 16-byte load per thread
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // raw input values of 8 channels of row m
+  auto load_raw = [&](int64_t m, int c, float r[8]) {
+    if (x16in && c + 8 <= C) {                           // bf16 input: one 16-byte load per thread
       const bf16x8 tb = *reinterpret_cast<const bf16x8*>(x16in + m * ldx + c);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float4 s = make_float4(1.f, 1.f, 1.f, 1.f), f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (scale) {
-          s = *reinterpret_cast<const float4*>(scale + (size_t)b * Cs + c + 4 * h);
-          f = *reinterpret_cast<const float4*>(shift + (size_t)b * Cs + c + 4 * h);
-        }
-        const float t0 = (float)tb[4 * h], t1 = (float)tb[4 * h + 1], t2 = (float)tb[4 * h + 2], t3 = (float)tb[4 * h + 3];
-        r[4 * h] = t0; r[4 * h + 1] = t1; r[4 * h + 2] = t2; r[4 * h + 3] = t3;
-        v[4 * h] = act_apply(fmaf(t0, s.x, f.x), act);
-        v[4 * h + 1] = act_apply(fmaf(t1, s.y, f.y), act);
-        v[4 * h + 2] = act_apply(fmaf(t2, s.z, f.z), act);
-        v[4 * h + 3] = act_apply(fmaf(t3, s.w, f.w), act);
-      }
-    } else {
+      for (int j = 0; j < 8; ++j) r[j] = (float)tb[j];
+      return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f), s = t, f = t;
-      const bool ok = c + 4 * h < C;                     // C is a multiple of 4
-      if (ok) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c + 4 * h < C) {                               // C is a multiple of 4
         if (x16in) {
           const bf16x4 tb = *reinterpret_cast<const bf16x4*>(x16in + m * ldx + c + 4 * h);
           t = make_float4((float)tb[0], (float)tb[1], (float)tb[2], (float)tb[3]);
         } else {
           t = *reinterpret_cast<const float4*>(x + m * ldx + c + 4 * h);
         }
-        if (scale) {
-          s = *reinterpret_cast<const float4*>(scale + (size_t)b * Cs + c + 4 * h);
-          f = *reinterpret_cast<const float4*>(shift + (size_t)b * Cs + c + 4 * h);
-        } else {
-          s = make_float4(1.f, 1.f, 1.f, 1.f);
-        }
       }
       r[4 * h] = t.x; r[4 * h + 1] = t.y; r[4 * h + 2] = t.z; r[4 * h + 3] = t.w;
-      v[4 * h] = ok ? act_apply(fmaf(t.x, s.x, f.x), act) : 0.f;
-      v[4 * h + 1] = ok ? act_apply(fmaf(t.y, s.y, f.y), act) : 0.f;
-      v[4 * h + 2] = ok ? act_apply(fmaf(t.z, s.z, f.z), act) : 0.f;
-      v[4 * h + 3] = ok ? act_apply(fmaf(t.w, s.w, f.w), act) : 0.f;
     }
+  };
+  auto finish = [&](int64_t m, int c, const float r[8], const float4 s[2], const float4 f[2]) {
+    float v[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool ok = c + 4 * h < C;
+      v[4 * h] = ok ? act16(fmaf(r[4 * h], s[h].x, f[h].x), act) : 0.f;
+      v[4 * h + 1] = ok ? act16(fmaf(r[4 * h + 1], s[h].y, f[h].y), act) : 0.f;
+      v[4 * h + 2] = ok ? act16(fmaf(r[4 * h + 2], s[h].z, f[h].z), act) : 0.f;
+      v[4 * h + 3] = ok ? act16(fmaf(r[4 * h + 3], s[h].w, f[h].w), act) : 0.f;
     }
     bf16x8 o, q;
 #pragma unroll
@@ -1076,6 +1084,52 @@ __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C
       w.y = pack_e4m3x4(make_float4(v[4], v[5], v[6], v[7]));
       *reinterpret_cast<uint2*>(out8 + m * ld8 + c) = w;
     }
+  };
+  float4 ks[2], kf[2];
+  ks[0] = ks[1] = make_float4(1.f, 1.f, 1.f, 1.f); kf[0] = kf[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (scale && (C % 8) == 0 && (stride % C8) == 0 && stride / C8 <= HW) {
+    const int pstep = (int)(stride / C8);
+    const int p0 = (int)fd_c8.div((unsigned)gtid), c = ((int)gtid - p0 * C8) * 8;
+    const int nb = (int)(M / HW);
+    for (int b = 0; b < nb; ++b) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ks[h] = *reinterpret_cast<const float4*>(scale + (size_t)b * Cs + c + 4 * h);
+        kf[h] = *reinterpret_cast<const float4*>(shift + (size_t)b * Cs + c + 4 * h);
+      }
+      const int64_t mb = (int64_t)b * HW;
+      int pp = p0;
+      for (; pp + pstep < HW; pp += 2 * pstep) {
+        float r0[8], r1[8];
+        load_raw(mb + pp, c, r0);
+        load_raw(mb + pp + pstep, c, r1);
+        finish(mb + pp, c, r0, ks, kf);
+        finish(mb + pp + pstep, c, r1, ks, kf);
+      }
+      if (pp < HW) {
+        float r0[8];
+        load_raw(mb + pp, c, r0);
+        finish(mb + pp, c, r0, ks, kf);
+      }
+    }
+    return;
+  }
+  const bool small = total < (int64_t(1) << 31);        // 32-bit indices with exact magic-number division (the usual case)
+  for (int64_t i = gtid; i < total; i += stride) {
+    const int64_t m = small ? (int64_t)fd_c8.div((unsigned)i) : i / C8;
+    const int c = (int)(i - m * C8) * 8;
+    const int b = small ? (int)fd_hw.div((unsigned)m) : (int)(m / HW);
+    if (scale) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (c + 4 * h < C) {
+          ks[h] = *reinterpret_cast<const float4*>(scale + (size_t)b * Cs + c + 4 * h);
+          kf[h] = *reinterpret_cast<const float4*>(shift + (size_t)b * Cs + c + 4 * h);
+        }
+    }
+    float r[8];
+    load_raw(m, c, r);
+    finish(m, c, r, ks, kf);
   }
 }
 
@@ -1165,7 +1219,7 @@ bool gemm16_supported(const IGemm& p) {
   const int al = p.f8 ? 16 : 8;       // a 16-byte chunk holds 16 e4m3 or 8 bf16 K elements
   // (an output is required: a launch with every output pointer NULL would run its epilogue into address 0)
   return p.A16 && p.Wt16 && p.zero16 && (p.out || p.out16 || p.out8 || p.pk_q) && (!p.out || p.ldo >= (p.sel_C ? p.sel_C : p.Cout)) &&
-         (!p.out16 || p.ldo16 > 0) && (!p.out8 || p.ldo8 > 0) && (!p.res || p.ldres > 0) && (!p.mul || p.ldmul > 0) && (!p.tb || p.ldtb > 0) &&
+         (!p.out16 || p.ldo16 > 0) && (!p.out8 || p.ldo8 > 0) && ((!p.res && !p.res16) || p.ldres > 0) && (!p.mul || p.ldmul > 0) && (!p.tb || p.ldtb > 0) &&
          (p.Cin % al) == 0 && (p.lda16 % al) == 0 && (p.Cout % 4) == 0 &&
          p.store == STORE_NHWC && p.pro_mask == MASK_NONE && !p.scale && p.pro_act == ACT_NONE && !(p.f8 && p.pk_q);
 }
@@ -1174,7 +1228,7 @@ void launch_gemm16(const IGemm& p, hipStream_t stream) {
   if (!gemm16_supported(p)) throw std::runtime_error("gemm16: unsupported operand layout");
   if (p.pk_q && !((p.pk_D == 8 || p.pk_D == 16 || p.pk_D == 32) && p.pk_heads > 0 && ((p.pk_heads * p.pk_D) % 64) == 0 &&
                   p.Cout == 3 * p.pk_heads * p.pk_D && p.taps == 1 && p.bias && p.pk_kv && p.pk_kmax && p.pk_qmax &&
-                  ((p.H * p.W) % 32) == 0 && p.pk_nt * 32 == p.H * p.W && p.epi_act == ACT_NONE && !p.mul && !p.res && !p.tb))
+                  ((p.H * p.W) % 32) == 0 && p.pk_nt * 32 == p.H * p.W && p.epi_act == ACT_NONE && !p.mul && !p.res && !p.res16 && !p.tb))
     throw std::runtime_error("gemm16: fused qkv packing needs head_dim 8, 16 or 32 with heads * head_dim a multiple of 64, whole 32-token tiles, plain epilogue");
   if (p.Cinb && !(p.A16b && p.Wt16b && (p.Cinb % 8) == 0 && (p.lda16b % 8) == 0))
     throw std::runtime_error("gemm16: second K segment needs bf16 operands with channel counts that are multiples of 8");

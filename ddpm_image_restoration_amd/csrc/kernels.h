@@ -33,6 +33,7 @@ struct IGemm {
   const float* rowscale = nullptr;            // [B]
   int epi_mask = MASK_NONE;
   const float* res = nullptr; int ldres = 0;
+  const void* res16 = nullptr;                // gemm16.hip: the residual as a bf16 tensor instead (same ldres; bf16 activation stream)
   // output
   float* out = nullptr; int ldo = 0; int store = STORE_NHWC;
   // DMA-streamed bf16 path (gemm16.hip): A already holds what the GEMM consumes, as bf16 [B*H*W][lda16]
@@ -156,11 +157,26 @@ void launch_freq_gate_fused(const float* x, const float* dct, const void* w1, co
 // of the output per (sample, block, group), [B][(H/bs)*(W/bs)][8][2] doubles, for launch_gn_from_partials
 void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int bs,
                             const float* mats, int per_channel, float mix_in, float mix_t, hipStream_t s,
-                            void* low16 = nullptr, void* high16 = nullptr, int low = 0, double* gn_partial_out = nullptr);
+                            void* low16 = nullptr, void* high16 = nullptr, int low = 0, double* gn_partial_out = nullptr, int io16 = 0);
+// (io16: `in` / `out` are bf16 tensors -- the head's mixed transform in the bf16 activation stream)
 bool block_transform_gn_fusable(int H, int W, int C, int bs);
 // fold [B][splits][G][2] double partials (any producer) into per-(b,c) scale / shift; n_per_group = elements per (sample, group)
+// (ldsc / zero_to as in launch_gn_scale_shift: one half of a concat input)
 void launch_gn_from_partials(const double* partial, int splits, int B, double n_per_group, int C, int G, const float* gamma,
-                             const float* beta, float* scale, float* shift, hipStream_t stream);
+                             const float* beta, float* scale, float* shift, hipStream_t stream, int ldsc = 0, int zero_to = -1);
+// Inter-block stream passes with GroupNorm statistics (pointwise.hip stream_k; bf16 / fp8 mode): NHWC tensors with 16-byte aligned
+// rows, 16 bytes * 2^k of channels per pixel.  2x2 max-pool / bilinear x2 (torch semantics as the plain kernels) / statistics
+// alone; with `partial` (>= B * G * 512 * 2 doubles; stream_stats_supported: G <= 8 groups of 16 bytes * 2^k channels) the
+// GroupNorm partial sums of the produced tensor come along.  Return value: splits per sample for launch_gn_from_partials
+// (0 without statistics).  *_16: the bf16 activation stream (results rounded to bf16); *_stats: the fp32 stream.
+bool stream_stats_supported(int C, int G, int elem_bytes);
+int launch_stats16(const void* x16, int ldx, int B, int H, int W, int C, int G, double* partial, hipStream_t s);
+int launch_maxpool2_16(const void* in16, int ldi, void* out16, int ldo, int B, int H, int W, int C, hipStream_t s,
+                       double* partial = nullptr, int G = 0);
+int launch_upsample2_16(const void* in16, int ldi, void* out16, int ldo, int B, int H, int W, int C, hipStream_t s,
+                        double* partial = nullptr, int G = 0);
+int launch_maxpool2_stats(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, hipStream_t s, double* partial, int G);
+int launch_upsample2_stats(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, hipStream_t s, double* partial, int G);
 
 // out = a * b * c * d (+ base)   elementwise over [M][C] with per-tensor strides; null pointers are skipped
 // out = base + xt * (0.25 * sum of the four bilinearly upsampled S x S gate maps, S = 1,2,4,8, stored back to back) * col * edge

@@ -21,6 +21,21 @@ struct HostTensor {
 };
 
 // bump allocator over one device allocation; dry run (base == nullptr) only measures
+// A tensor of the activation stream BETWEEN residual blocks (block outputs, pooled / upsampled tensors, concat buffers): fp32,
+// or bf16 where the bf16 activation stream is on (bf16 / fp8 mode of the DCT families; model.hip Context::stream16()).
+struct ActBuf {
+  void* p = nullptr; int ld = 0; bool h = false;      // h: elements are bf16
+  ActBuf at(size_t elems) const { ActBuf a = *this; a.p = static_cast<char*>(p) + elems * (h ? 2 : 4); return a; }
+  float* f() const { return static_cast<float*>(p); }
+};
+// Where norm1's statistics of a block input come from (all empty: a pass over the input).
+struct InStats {
+  const double* skip_sums = nullptr;   // up block: sums of the skip half, from the down block's conv_out epilogue
+  int partial_splits = 0;              // bf16 stream: plan_.gn_partial holds the sums the max-pool (whole input) or the bilinear x2 (the
+                                       // upsampled half of a concat input) left, written with this many splits per sample
+  bool concat = false;                 // up block: input = cat[upsampled, skip]; its 8 groups split 4 + 4 over the halves
+};
+
 struct Arena {
   char* base = nullptr;
   size_t off = 0;
@@ -141,10 +156,10 @@ class Context {
     int B = 0, H = 0, W = 0;
     char* base = nullptr; size_t bytes = 0;
     float* x4 = nullptr;
-    float* cat[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // concat inputs of up5..up1, index = level
-    float* pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // pooled inputs, index = level (1..5)
-    float *bb0 = nullptr, *bb1 = nullptr, *bb2 = nullptr;
-    float* u[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // outputs of up blocks, index = level
+    ActBuf cat[5];   // concat inputs of up5..up1, index = level
+    ActBuf pin[6];   // pooled inputs, index = level (1..5)
+    ActBuf bb0, bb1, bb2;
+    ActBuf u[5];     // outputs of up blocks, index = level
     float *hA = nullptr, *hB = nullptr, *qkv = nullptr, *att = nullptr, *xd = nullptr, *hid = nullptr, *S = nullptr;
     float *xt = nullptr, *avg = nullptr, *col = nullptr, *edge = nullptr, *pool = nullptr, *pool8 = nullptr, *pg1 = nullptr, *pg2 = nullptr;
     unsigned char* attn_ws = nullptr;
@@ -186,10 +201,13 @@ class Context {
   void prof_close_forward(hipStream_t s);
   // out_stats: a down block leaves the GroupNorm sums of its output there (conv_out's epilogue); in_skip_stats: an up block
   // takes the statistics of the skip half of its concat input from there instead of reading that half again
-  void run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s,
-                 double* out_stats = nullptr, const double* in_skip_stats = nullptr);
-  void run_block16(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest, hipStream_t s,
-                   double* out_stats, const double* in_skip_stats);
+  void run_block(const BlockW& bw, ActBuf in, int H, int W, ActBuf dest, hipStream_t s, double* out_stats = nullptr, InStats st = InStats());
+  void run_block16(const BlockW& bw, ActBuf in, int H, int W, ActBuf dest, hipStream_t s, double* out_stats, InStats st);
+  // bf16 / fp8 mode, DCT families: the activation stream between blocks is bf16 (the reference's autocast rounds every conv
+  // output to bf16 too); AVIF and fp32 mode keep fp32
+  bool stream16() const;
+  int stream16_opt_ = -1;   // option "bf16_activation_stream": -1 fp8 mode only (default), 0 never, 1 bf16 mode too
+  int upsample(ActBuf in, int C, ActBuf cat, int B, int Hi, int Wi, hipStream_t s);
   bool skip_stats_fused(int level, int B, int H, int W) const;
   void conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override = nullptr);
   bool use_gemm16() const { return cfg.dtype == DDPMIR_BF16 || cfg.dtype == DDPMIR_FP8; }

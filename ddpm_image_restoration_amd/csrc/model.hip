@@ -369,15 +369,25 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
   auto hw = [&](int lvl) { return (size_t)(H >> lvl) * (W >> lvl); };
   const size_t M0 = (size_t)B * H * W;
   p.x4 = a.take<float>(M0 * 4);
+  // the activation stream between blocks: bf16 tensors where stream16(), fp32 otherwise
+  const bool h = stream16();
+  auto act = [&](size_t pixels, int c) {
+    ActBuf t; t.ld = c; t.h = h;
+    if (h) t.p = a.take<unsigned short>(pixels * c); else t.p = a.take<float>(pixels * c);
+    return t;
+  };
   const int cat_c[5] = {128, 256, 512, 1024, 1024};            // concat width at level 0..4
-  for (int l = 0; l < 5; ++l) p.cat[l] = a.take<float>((size_t)B * hw(l) * cat_c[l]);
+  for (int l = 0; l < 5; ++l) p.cat[l] = act((size_t)B * hw(l), cat_c[l]);
   const int pin_c[6] = {0, 64, 128, 256, 512, 512};            // pooled input channels at level 1..5
-  for (int l = 1; l <= 5; ++l) p.pin[l] = a.take<float>((size_t)B * hw(l) * pin_c[l]);
-  p.bb0 = a.take<float>((size_t)B * hw(5) * 1024);
-  p.bb1 = a.take<float>((size_t)B * hw(5) * 1024);
-  p.bb2 = a.take<float>((size_t)B * hw(5) * 512);
+  for (int l = 1; l <= 5; ++l) p.pin[l] = act((size_t)B * hw(l), pin_c[l]);
+  p.bb0 = act((size_t)B * hw(5), 1024);
+  p.bb1 = act((size_t)B * hw(5), 1024);
+  p.bb2 = act((size_t)B * hw(5), 512);
   const int u_c[5] = {64, 64, 128, 256, 512};                  // up-block output channels at level 0..4
-  for (int l = 0; l < 5; ++l) p.u[l] = a.take<float>((size_t)B * hw(l) * u_c[l]);
+  for (int l = 1; l < 5; ++l) p.u[l] = act((size_t)B * hw(l), u_c[l]);
+  // (up5's output stays fp32: the head's blockwise transform maps a thread to a channel, and its 2-byte accesses on a bf16
+  // tensor ran 4x slower than the 4-byte ones -- 0.98 vs 0.24 ms at 512 x 512, B = 8)
+  p.u[0].p = a.take<float>((size_t)B * hw(0) * u_c[0]); p.u[0].ld = u_c[0]; p.u[0].h = false;
   // per-block scratch: max over blocks of pixels*cout is at level 0 (64 ch); deeper levels never exceed it
   size_t mc = 0;
   for (auto& d : kBlocks) mc = std::max(mc, (size_t)B * hw(d.level) * d.cout);
@@ -594,6 +604,12 @@ void Context::set_option(const std::string& name, double value) {
     blob_bytes_ = 0;
     return;
   }
+  if (name == "bf16_activation_stream") {   // -1: fp8 mode only (default); 0: never; 1: bf16 mode too.  Re-plans (buffers change type)
+    if (value != -1 && value != 0 && value != 1) throw std::invalid_argument("bf16_activation_stream must be -1, 0 or 1");
+    stream16_opt_ = (int)value;
+    free_plan();
+    return;
+  }
   throw std::invalid_argument("unknown option " + name);
 }
 
@@ -730,22 +746,37 @@ void Context::conv8(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_o
 // bf16 mode, DCT families: every GEMM input is a bf16 tensor written once by its producer (GroupNorm-apply pass,
 // previous GEMM epilogue, attention, DCT kernel), so both GEMM operands stream by LDS-DMA (gemm16.hip).
 // The fp32 tensors that carry the residual stream and the GroupNorm statistics stay fp32.
-void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest,
-                          hipStream_t s, double* out_stats, const double* in_skip_stats) {
+bool Context::stream16() const {
+  if (!use_gemm16() || cfg.arch == DDPMIR_ARCH_AVIF) return false;
+  return stream16_opt_ < 0 ? cfg.dtype == DDPMIR_FP8 : stream16_opt_ != 0;
+}
+
+void Context::run_block16(const BlockW& bw, ActBuf in, int H, int W, ActBuf dest, hipStream_t s, double* out_stats, InStats st) {
   Plan& p = plan_;
   const int B = fb_, C = bw.cout, HW = H * W;
   const int cin8 = round_up(bw.cin, 8);
+  const int ldin = in.ld;
+  const bool in16 = in.h;   // bf16 activation stream: the input is read as bf16 and doubles as the 1x1 shortcut's operand
 #define STAGE(what) debug_stage(s, bw.name.c_str(), what, B, H, W, C)
   IGemm g; g.B = B; g.H = H; g.W = W; g.bs = k.dct_block; g.low = k.low_size;
   // norm1 -> conv1 (+ bias + time projection)
-  if (in_skip_stats) {
-    // up block: the input is cat[upsampled, skip] and its 8 groups split 4 + 4 over the halves.  The skip half's sums came out
-    // of the down block's conv_out epilogue (no pass over that half); only the upsampled half is read here.
+  // statistics of (a channel range of) the input: the sums the producing max-pool / bilinear pass left where there are any,
+  // the skip half's sums from the down block's conv_out epilogue, else a pass over the tensor
+  auto norm1_part = [&](int c0, int C1, int G, const double* sums, int splits, int ld, int zero_to) {
+    const float *ga = bw.n1g + c0, *be = bw.n1b + c0;
+    float *sc = p.sc1 + c0, *sh = p.sh1 + c0;
+    if (sums) { launch_gn_from_sums(sums, B, HW, C1, G, ga, be, sc, sh, s, ld, zero_to); return; }
+    if (!splits && in16) splits = launch_stats16(in.at(c0).p, ldin, B, H, W, C1, G, p.gn_partial, s);
+    if (splits) launch_gn_from_partials(p.gn_partial, splits, B, (double)HW * (C1 / G), C1, G, ga, be, sc, sh, s, ld, zero_to);
+    else launch_gn_scale_shift(in.f() + c0, ldin, B, HW, C1, G, ga, be, p.gn_partial, sc, sh, s, ld, zero_to);
+  };
+  if (st.concat) {
+    // up block: the input is cat[upsampled, skip] and its 8 groups split 4 + 4 over the halves
     const int ch = bw.cin / 2, ld = round_up(bw.cin, 4);
-    launch_gn_scale_shift(in, ldin, B, HW, ch, 4, bw.n1g, bw.n1b, p.gn_partial, p.sc1, p.sh1, s, ld, 0);
-    launch_gn_from_sums(in_skip_stats, B, HW, ch, 4, bw.n1g + ch, bw.n1b + ch, p.sc1 + ch, p.sh1 + ch, s, ld, 0);
+    norm1_part(0, ch, 4, nullptr, st.partial_splits, ld, 0);
+    norm1_part(ch, ch, 4, st.skip_sums, 0, ld, 0);
   } else {
-    launch_gn_scale_shift(in, ldin, B, HW, bw.cin, gn_groups(bw.cin), bw.n1g, bw.n1b, p.gn_partial, p.sc1, p.sh1, s);
+    norm1_part(0, bw.cin, gn_groups(bw.cin), nullptr, st.partial_splits, 0, -1);
   }
   STAGE("norm1 statistics");
   // (3-channel image input: x4 carries a zero 4th channel, gn_finalize zeroes its scale/shift, a16 pads to 8)
@@ -758,8 +789,11 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   const bool fuse_gn = !no_gn_fuse && gemm16_can_fuse_gn(probe, gn_groups(C));
   // (DDPMIR_FP8: the deep 3x3 convs take their operand as e4m3 instead -- written by the same pass)
   const bool c1_f8 = bw.conv1.w8 != nullptr, c2_f8 = bw.conv2.w8 != nullptr, co_f8 = bw.conv_out.w8 != nullptr;
-  launch_gn_apply16(in, ldin, B, HW, bw.cinp, p.sc1, p.sh1, ACT_NONE, c1_f8 ? nullptr : p.a16, cin8, bw.has_shortcut ? p.x16 : nullptr,
-                    cin8, s, nullptr, 0, c1_f8 ? p.a8 : nullptr, bw.conv1.cin16);
+  launch_gn_apply16(in16 ? nullptr : in.f(), ldin, B, HW, bw.cinp, p.sc1, p.sh1, ACT_NONE, c1_f8 ? nullptr : p.a16, cin8,
+                    bw.has_shortcut && !in16 ? p.x16 : nullptr, cin8, s, nullptr, 0, c1_f8 ? p.a8 : nullptr, bw.conv1.cin16,
+                    in16 ? in.p : nullptr);
+  const void* xs16 = in16 ? in.p : p.x16;          // raw bf16 block input: operand of the 1x1 shortcut
+  const int ldxs = in16 ? ldin : cin8;
   STAGE("norm1 apply");
   // With the statistics taken from the fp32 accumulators, conv1's output is only ever read by the norm2-apply pass: it is
   // written once as bf16 (half the bytes out and in again); the deep levels (split-K, statistics pass over the tensor) keep fp32
@@ -858,7 +892,9 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
   STAGE("frequency block");
   // conv_out + residual; a 1x1 shortcut conv rides along as a second K segment of the same GEMM (identity shortcuts
   // are the plain fp32 residual)
-  IGemm co = g; co.A16 = p.S16; co.lda16 = C; co.out = dest; co.ldo = lddest;
+  IGemm co = g; co.A16 = p.S16; co.lda16 = C;
+  if (dest.h) { co.out16 = dest.p; co.ldo16 = dest.ld; } else { co.out = dest.f(); co.ldo = dest.ld; }
+  auto identity_residual = [&](IGemm& q) { if (in16) { q.res16 = in.p; q.ldres = ldin; } else { q.res = in.f(); q.ldres = ldin; } };
   if (out_stats) { co.gn_sums = out_stats; co.gn_groups = 4; }   // a down block's output is the skip half of an up block's norm1
   const bool split_sc = exp_switch("DDPMIR_SPLIT_SHORTCUT");   // A/B: separate shortcut GEMM
   if (co_f8) {
@@ -866,22 +902,23 @@ void Context::run_block16(const BlockW& bw, const float* in, int ldin, int H, in
     // same accumulators, with weights pre-multiplied by conv_out's power-of-two fp8 weight scale (BlockW::sc16s)
     co.A16 = p.S8;
     if (bw.has_shortcut) {
-      co.A16b = p.x16; co.lda16b = cin8; co.Wt16b = bw.sc16s; co.Cinb = bw.shortcut.cin16;
+      co.A16b = xs16; co.lda16b = ldxs; co.Wt16b = bw.sc16s; co.Cinb = bw.shortcut.cin16;
       conv8(bw.conv_out, co, s, bw.co_bias);
     } else {
-      co.res = in; co.ldres = ldin;
+      identity_residual(co);
       conv8(bw.conv_out, co, s);
     }
   } else if (bw.has_shortcut && !split_sc) {
-    co.A16b = p.x16; co.lda16b = cin8; co.Wt16b = bw.shortcut.w16; co.Cinb = bw.shortcut.cin16;
+    co.A16b = xs16; co.lda16b = ldxs; co.Wt16b = bw.shortcut.w16; co.Cinb = bw.shortcut.cin16;
     conv16(bw.conv_out, co, s, bw.co_bias);
   } else {
     if (bw.has_shortcut) {
-      IGemm sc = g; sc.A16 = p.x16; sc.lda16 = cin8; sc.out = dest; sc.ldo = lddest;
+      IGemm sc = g; sc.A16 = xs16; sc.lda16 = ldxs;
+      if (dest.h) { sc.out16 = dest.p; sc.ldo16 = dest.ld; co.res16 = dest.p; } else { sc.out = dest.f(); sc.ldo = dest.ld; co.res = dest.f(); }
       conv16(bw.shortcut, sc, s);
-      co.res = dest; co.ldres = lddest;
+      co.ldres = dest.ld;
     } else {
-      co.res = in; co.ldres = ldin;
+      identity_residual(co);
     }
     conv16(bw.conv_out, co, s);
   }
@@ -899,9 +936,10 @@ bool Context::skip_stats_fused(int level, int B, int H, int W) const {
   return gemm16_can_fuse_gn(probe, 4);
 }
 
-void Context::run_block(const BlockW& bw, const float* in, int ldin, int H, int W, float* dest, int lddest,
-                        hipStream_t s, double* out_stats, const double* in_skip_stats) {
-  if (use_gemm16()) { run_block16(bw, in, ldin, H, W, dest, lddest, s, out_stats, in_skip_stats); return; }
+void Context::run_block(const BlockW& bw, ActBuf in_a, int H, int W, ActBuf dest_a, hipStream_t s, double* out_stats, InStats st) {
+  if (use_gemm16()) { run_block16(bw, in_a, H, W, dest_a, s, out_stats, st); return; }
+  const float* in = in_a.f(); const int ldin = in_a.ld;
+  float* dest = dest_a.f(); const int lddest = dest_a.ld;
   Plan& p = plan_;
   const int B = fb_, C = bw.cout;
   IGemm g; g.B = B; g.H = H; g.W = W;
@@ -969,6 +1007,16 @@ void Context::prof_close_forward(hipStream_t s) {
     if (it->cls == PROF_FWD) { DDPMIR_HIP_CHECK(hipEventRecord(it->b, s)); break; }
 }
 
+// bilinear x2 of `in` (C channels) into the first half of the concat buffer `cat`; in bf16 / fp8 mode the pass also leaves the
+// GroupNorm(4 groups) sums of what it wrote in plan_.gn_partial: returns their splits per sample (0: none)
+int Context::upsample(ActBuf in, int C, ActBuf cat, int B, int Hi, int Wi, hipStream_t s) {
+  if (in.h) return launch_upsample2_16(in.p, C, cat.p, cat.ld, B, Hi, Wi, C, s, plan_.gn_partial, 4);
+  if (use_gemm16() && stream_stats_supported(C, 4, 4) && !exp_switch("DDPMIR_NO_STREAM_STATS"))
+    return launch_upsample2_stats(in.f(), C, cat.f(), cat.ld, B, Hi, Wi, C, s, plan_.gn_partial, 4);
+  launch_upsample2(in.f(), C, cat.f(), cat.ld, B, Hi, Wi, C, s);
+  return 0;
+}
+
 void Context::fwd_head(const float* x, const float* t, const float* cl, int row0, int nb, bool whole, hipStream_t s) {
   Plan& p = plan_;
   const int H = p.H, W = p.W;
@@ -991,7 +1039,8 @@ void Context::fwd_head(const float* x, const float* t, const float* cl, int row0
     // the skip tensor goes straight into the second half of up5's concat buffer
     debug_stage(s, "forward", "image layout + time embedding", nb, H, W, 3);
     double* st0 = skip_stats_fused(0, nb, H, W) ? p.skip_sums[0] + gn_sums_doubles(row0, (int)HW, 4) : nullptr;
-    run_block(blocks_[0], x4, 4, H, W, p.cat[0] + (size_t)row0 * HW * 128 + 64, 128, s, st0);
+    ActBuf img; img.p = x4; img.ld = 4;
+    run_block(blocks_[0], img, H, W, p.cat[0].at((size_t)row0 * HW * 128 + 64), s, st0);
   }
   if (!whole) prof_close_forward(s);
 }
@@ -1008,26 +1057,37 @@ void Context::fwd_mid(int B, bool whole, hipStream_t s) {
   const int skip_off[5] = {64, 128, 256, 512, 512};
   const int skip_c[5] = {64, 128, 256, 512, 512};
   // down path
-  launch_maxpool2(p.cat[0] + skip_off[0], cat_c[0], p.pin[1], skip_c[0], B, hh(0), ww(0), skip_c[0], s);
-  const float* in = p.pin[1]; int ldin = skip_c[0];
-  for (int l = 1; l < 5; ++l) {
-    float* d = p.cat[l] + skip_off[l];
-    run_block(blocks_[l], in, ldin, hh(l), ww(l), d, cat_c[l], s, skip_stats_fused(l, B, hh(l), ww(l)) ? p.skip_sums[l] : nullptr);
-    launch_maxpool2(d, cat_c[l], p.pin[l + 1], skip_c[l], B, hh(l), ww(l), skip_c[l], s);
+  // (bf16 stream: the pool / bilinear pass also leaves the GroupNorm sums of what it wrote -- the next block's norm1 input)
+  auto pool = [&](int l) {   // level l's skip tensor -> pin[l + 1]; returns the splits of the sums left in p.gn_partial
+    const ActBuf src = p.cat[l].at(skip_off[l]);
+    int splits = 0;
+    const int G = gn_groups(skip_c[l]);
+    if (src.h) splits = launch_maxpool2_16(src.p, cat_c[l], p.pin[l + 1].p, skip_c[l], B, hh(l), ww(l), skip_c[l], s, p.gn_partial, G);
+    else if (use_gemm16() && stream_stats_supported(skip_c[l], G, 4) && !exp_switch("DDPMIR_NO_STREAM_STATS"))
+      splits = launch_maxpool2_stats(src.f(), cat_c[l], p.pin[l + 1].f(), skip_c[l], B, hh(l), ww(l), skip_c[l], s, p.gn_partial, G);
+    else launch_maxpool2(src.f(), cat_c[l], p.pin[l + 1].f(), skip_c[l], B, hh(l), ww(l), skip_c[l], s);
     debug_stage(s, "forward", "max-pool", B, hh(l), ww(l), skip_c[l]);
-    in = p.pin[l + 1]; ldin = skip_c[l];
+    return splits;
+  };
+  InStats st; st.partial_splits = pool(0);
+  for (int l = 1; l < 5; ++l) {
+    run_block(blocks_[l], p.pin[l], hh(l), ww(l), p.cat[l].at(skip_off[l]), s,
+              skip_stats_fused(l, B, hh(l), ww(l)) ? p.skip_sums[l] : nullptr, st);
+    st.partial_splits = pool(l);
   }
-  run_block(blocks_[5], p.pin[5], 512, hh(5), ww(5), p.bb0, 1024, s);
-  run_block(blocks_[6], p.bb0, 1024, hh(5), ww(5), p.bb1, 1024, s);
-  run_block(blocks_[7], p.bb1, 1024, hh(5), ww(5), p.bb2, 512, s);
+  run_block(blocks_[5], p.pin[5], hh(5), ww(5), p.bb0, s, nullptr, st);
+  run_block(blocks_[6], p.bb0, hh(5), ww(5), p.bb1, s);
+  run_block(blocks_[7], p.bb1, hh(5), ww(5), p.bb2, s);
   // up path: cat[upsampled, skip]                           webp_inference.py:389-393
-  const float* prev = p.bb2; int prev_c = 512;
+  ActBuf prev = p.bb2; int prev_c = 512;
   for (int l = 4; l >= 1; --l) {
-    launch_upsample2(prev, prev_c, p.cat[l], cat_c[l], B, hh(l + 1), ww(l + 1), prev_c, s);
+    InStats us;
+    us.skip_sums = skip_stats_fused(l, B, hh(l), ww(l)) ? p.skip_sums[l] : nullptr;
+    us.partial_splits = upsample(prev, prev_c, p.cat[l], B, hh(l + 1), ww(l + 1), s);
+    us.concat = us.partial_splits || us.skip_sums != nullptr;
     debug_stage(s, "forward", "bilinear x2", B, hh(l + 1), ww(l + 1), prev_c);
     const BlockW& bw = blocks_[8 + (4 - l)];
-    run_block(bw, p.cat[l], cat_c[l], hh(l), ww(l), p.u[l], bw.cout, s, nullptr,
-              skip_stats_fused(l, B, hh(l), ww(l)) ? p.skip_sums[l] : nullptr);
+    run_block(bw, p.cat[l], hh(l), ww(l), p.u[l], s, nullptr, us);
     prev = p.u[l]; prev_c = bw.cout;
   }
   if (!whole) prof_close_forward(s);
@@ -1042,27 +1102,38 @@ void Context::fwd_tail(float* out, int row0, int nb, bool whole, hipStream_t s) 
   SideRows rows(p.tproj, p.boost, p.boost2, p.constmix, row0, nt_total_);
   const BlockW& bw = blocks_[12];
   const int prev_c = blocks_[11].cout;
-  float* cat0 = p.cat[0] + (size_t)row0 * HW * 128;
-  float* u0 = p.u[0] + (size_t)row0 * HW * bw.cout;
-  launch_upsample2(p.u[1] + (size_t)row0 * (HW / 4) * prev_c, prev_c, cat0, 128, nb, H >> 1, W >> 1, prev_c, s);
-  run_block(bw, cat0, 128, H, W, u0, bw.cout, s, nullptr,
-            skip_stats_fused(0, nb, H, W) ? p.skip_sums[0] + gn_sums_doubles(row0, (int)HW, 4) : nullptr);
+  const ActBuf cat0 = p.cat[0].at((size_t)row0 * HW * 128);
+  const ActBuf u0a = p.u[0].at((size_t)row0 * HW * bw.cout);
+  const ActBuf u1 = p.u[1].at((size_t)row0 * (HW / 4) * prev_c);
+  InStats us;
+  us.skip_sums = skip_stats_fused(0, nb, H, W) ? p.skip_sums[0] + gn_sums_doubles(row0, (int)HW, 4) : nullptr;
+  us.partial_splits = upsample(u1, prev_c, cat0, nb, H >> 1, W >> 1, s);
+  us.concat = us.partial_splits || us.skip_sums != nullptr;
+  run_block(bw, cat0, H, W, u0a, s, nullptr, us);
+  float* u0 = u0a.f();   // (fp32 stream; the bf16 stream reads u0a below)
   // head: u5 + mix * transform(u5) -> GroupNorm(8) -> SiLU -> conv 64->3 -> tanh     webp_inference.py:396-399
   const bool head_gn_fused = use_gemm16() && cfg.arch != DDPMIR_ARCH_AVIF && block_transform_gn_fusable(H, W, 64, k.dct_block) &&
                              !exp_switch("DDPMIR_NO_HEAD_GN_FUSE");
   if (cfg.arch == DDPMIR_ARCH_AVIF)
     avif_transform(head_at_, u0, 64, 64, H, W, p.xd, p.hid, p.S, 64, p.constmix, u0, 64, s);
+  else if (u0a.h)   // bf16 stream: u5 in, the mixed tensor out as bf16 (its only reader is the GroupNorm-apply pass below)
+    launch_block_transform(u0, 64, reinterpret_cast<float*>(p.S16), 64, nb, H, W, 64, k.dct_block, head_dct_, 0, 1.0f, k.head_mix, s,
+                           nullptr, nullptr, 0, head_gn_fused ? p.gn_sums : nullptr, 1);
   else
     launch_block_transform(u0, 64, p.S, 64, nb, H, W, 64, k.dct_block, head_dct_, 0, 1.0f, k.head_mix, s, nullptr, nullptr, 0,
                            head_gn_fused ? p.gn_sums : nullptr);
   // (DCT families, bf16 / fp8 mode: the mix pass also emits the GroupNorm sums of its output)
   if (head_gn_fused)
     launch_gn_from_partials(p.gn_sums, (H / k.dct_block) * (W / k.dct_block), nb, (double)H * W * 8, 64, 8, head_g_, head_b_, p.sc1, p.sh1, s);
+  else if (u0a.h)
+    launch_gn_from_partials(p.gn_partial, launch_stats16(p.S16, 64, nb, H, W, 64, 8, p.gn_partial, s), nb, (double)H * W * 8, 64, 8,
+                            head_g_, head_b_, p.sc1, p.sh1, s);
   else
     launch_gn_scale_shift(p.S, 64, nb, H * W, 64, 8, head_g_, head_b_, p.gn_partial, p.sc1, p.sh1, s);
   if (use_gemm16()) {   // SiLU(GN(.)) as a bf16 operand -> DMA GEMM with Cout padded to 4 -> tanh + NCHW in one pass
     float* x4 = p.x4 + (size_t)row0 * HW * 4;          // the lane's image rows are free again
-    launch_gn_apply16(p.S, 64, nb, H * W, 64, p.sc1, p.sh1, ACT_SILU, p.a16, 64, nullptr, 0, s);
+    launch_gn_apply16(u0a.h ? nullptr : p.S, 64, nb, H * W, 64, p.sc1, p.sh1, ACT_SILU, p.a16, 64, nullptr, 0, s, nullptr, 0, nullptr, 0,
+                      u0a.h ? p.S16 : nullptr);
     IGemm hc; hc.B = nb; hc.H = H; hc.W = W; hc.A16 = p.a16; hc.lda16 = 64; hc.out = x4; hc.ldo = 4;
     conv16(head_conv_, hc, s);
     launch_nhwc4_to_nchw3_tanh(x4, out, nb, H, W, s);

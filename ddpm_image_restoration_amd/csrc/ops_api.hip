@@ -498,6 +498,53 @@ int ddpmir_op_freq_gates_bf16(const float* x, int B, int H, int W, int C, int bs
   });
 }
 
+// Inter-block stream passes (pointwise.hip stream_k).  mode 0: statistics of x alone (bf16 only); 1: 2x2 max-pool; 2: bilinear x2.
+// f32 = 0: the bf16 activation stream -- x is rounded to bf16 on the way in, out (mode 1 / 2) is the bf16 result widened to
+// fp32; f32 = 1: the fp32 stream.  scale / shift [B][C] are the GroupNorm affine folded from the partial sums the pass left
+// (G groups over the C channels of the tensor the mode produces).
+int ddpmir_op_stream16(int mode, const float* x, int B, int H, int W, int C, int ldx, int G, const float* gamma, const float* beta,
+                       float* out, float* scale, float* shift, int f32) {
+  return guarded([&] {
+    Dev d;
+    if (ldx < C) ldx = C;
+    const size_t Mi = (size_t)B * H * W;
+    const int Ho = mode == 1 ? H / 2 : mode == 2 ? 2 * H : H, Wo = mode == 1 ? W / 2 : mode == 2 ? 2 * W : W;
+    const size_t Mo = (size_t)B * Ho * Wo;
+    double* part = d.alloc<double>((size_t)B * 8 * 512 * 2 + 64);
+    int splits = 0;
+    unsigned short* o16 = nullptr;
+    float* o32 = nullptr;
+    if (f32) {
+      if (mode == 0 || ldx != C) throw std::invalid_argument("fp32 stream: modes 1 and 2, dense rows");
+      const float* dx = d.up(x, Mi * C);
+      o32 = d.alloc<float>(Mo * C);
+      if (mode == 1) splits = launch_maxpool2_stats(dx, C, o32, C, B, H, W, C, nullptr, G ? part : nullptr, G);
+      else splits = launch_upsample2_stats(dx, C, o32, C, B, H, W, C, nullptr, G ? part : nullptr, G);
+    } else {
+      unsigned short* x16 = d.alloc<unsigned short>(Mi * ldx);
+      launch_gn_apply16(d.up(x, Mi * C), C, B, H * W, C, nullptr, nullptr, ACT_NONE, x16, ldx, nullptr, 0, nullptr);
+      o16 = d.alloc<unsigned short>(Mo * C);
+      if (mode == 0) splits = launch_stats16(x16, ldx, B, H, W, C, G, G ? part : nullptr, nullptr);
+      else if (mode == 1) splits = launch_maxpool2_16(x16, ldx, o16, C, B, H, W, C, nullptr, G ? part : nullptr, G);
+      else splits = launch_upsample2_16(x16, ldx, o16, C, B, H, W, C, nullptr, G ? part : nullptr, G);
+    }
+    if (G) {
+      float* sc = d.alloc<float>((size_t)B * C);
+      float* sh = d.alloc<float>((size_t)B * C);
+      launch_gn_from_partials(part, splits, B, (double)Ho * Wo * (C / G), C, G, d.up(gamma, C), d.up(beta, C), sc, sh, nullptr);
+      d.down(scale, sc, (size_t)B * C);
+      d.down(shift, sh, (size_t)B * C);
+    }
+    if (mode != 0 && f32) {
+      d.down(out, o32, Mo * C);
+    } else if (mode != 0) {
+      std::vector<unsigned short> h(Mo * C);
+      d.down(h.data(), o16, Mo * C);
+      for (size_t i = 0; i < h.size(); ++i) { unsigned int u = (unsigned int)h[i] << 16; memcpy(&out[i], &u, 4); }
+    }
+  });
+}
+
 int ddpmir_op_maxpool2(const float* x, int B, int H, int W, int C, float* out) {
   return guarded([&] {
     Dev d;

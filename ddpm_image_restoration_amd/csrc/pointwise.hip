@@ -200,6 +200,109 @@ __global__ void bilinear_k(const float* __restrict__ in, int ldi, float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------- pool / upsample with statistics
+// The tensors BETWEEN residual blocks (bf16 / fp8 mode): 2x2 max-pool, bilinear x2, or statistics alone over NHWC with 16-byte
+// accesses, for an fp32 stream (T = float, 4 channels per lane) or the bf16 activation stream (T = __bf16, 8 channels per lane;
+// results rounded to bf16 as the reference's autocast rounds every conv output):
+//   STATS  no output, sums of `in`          POOL  out = maxpool2(in)          UP  out = bilinear x2 (in)
+// When `partial` is given the pass also leaves the GroupNorm partial sums of the tensor it produces (of the values a consumer
+// will read), in gn_partial's layout [b][splits][G][2]: the statistics pass over a pooled / upsampled block input disappears.
+// A workgroup owns a run of output pixels of one sample; thread = (pixel slot, channel slot), so a thread's channels lie in
+// one group; lanes fold by xor-shuffles over the offsets that stay inside a group or step whole pixels.  Fixed order: the
+// statistics are bit-reproducible.
+typedef __bf16 h8_t __attribute__((ext_vector_type(8)));
+enum { S16_STATS = 0, S16_POOL = 1, S16_UP = 2 };
+
+template <typename T> struct LaneVec;
+template <> struct LaneVec<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float v[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void store(float* p, float v[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct LaneVec<__bf16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const __bf16* p, float v[8]) {
+    const h8_t t = *reinterpret_cast<const h8_t*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+  }
+  static __device__ __forceinline__ void store(__bf16* p, float v[8]) {   // v becomes what was stored
+    h8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o[j] = (__bf16)v[j]; v[j] = (float)o[j]; }
+    *reinterpret_cast<h8_t*>(p) = o;
+  }
+};
+
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void stream_k(const T* __restrict__ in, int ldi, T* __restrict__ out, int ldo, int Hi, int Wi,
+                                                int CL /* lanes per pixel */, int gl /* lanes per group */, int G, int splits, FastDiv fd_wo,
+                                                double* __restrict__ partial) {
+  constexpr int N = LaneVec<T>::N;
+  __shared__ double red[4][8][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const int Ho = MODE == S16_POOL ? Hi / 2 : MODE == S16_UP ? 2 * Hi : Hi;
+  const int Wo = MODE == S16_POOL ? Wi / 2 : MODE == S16_UP ? 2 * Wi : Wi;
+  const int HWo = Ho * Wo;
+  const int ppi = 256 / CL, slot = tid % CL, pslot = tid / CL;
+  const int p_begin = (int)((int64_t)sp * HWo / splits), p_end = (int)((int64_t)(sp + 1) * HWo / splits);
+  const T* ib = in + (size_t)b * Hi * Wi * ldi + slot * N;
+  double a1 = 0.0, a2 = 0.0;
+  for (int p = p_begin + pslot; p < p_end; p += ppi) {
+    float v[N];
+    if (MODE == S16_STATS) {
+      LaneVec<T>::load(ib + (size_t)p * ldi, v);
+    } else {
+      const int yo = (int)fd_wo.div((unsigned)p), xo = p - yo * Wo;
+      if (MODE == S16_POOL) {
+        const T* q = ib + ((size_t)(2 * yo) * Wi + 2 * xo) * ldi;
+        float t0[N], t1[N], t2[N];
+        LaneVec<T>::load(q, v); LaneVec<T>::load(q + ldi, t0);
+        LaneVec<T>::load(q + (size_t)Wi * ldi, t1); LaneVec<T>::load(q + (size_t)Wi * ldi + ldi, t2);
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = fmaxf(fmaxf(v[j], t0[j]), fmaxf(t1[j], t2[j]));
+      } else {
+        int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+        lin_coord(yo, Hi, 0.5f, y0, y1, wy0, wy1);
+        lin_coord(xo, Wi, 0.5f, x0, x1, wx0, wx1);
+        float v00[N], v01[N], v10[N], v11[N];
+        LaneVec<T>::load(ib + ((size_t)y0 * Wi + x0) * ldi, v00); LaneVec<T>::load(ib + ((size_t)y0 * Wi + x1) * ldi, v01);
+        LaneVec<T>::load(ib + ((size_t)y1 * Wi + x0) * ldi, v10); LaneVec<T>::load(ib + ((size_t)y1 * Wi + x1) * ldi, v11);
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = wy0 * (wx0 * v00[j] + wx1 * v01[j]) + wy1 * (wx0 * v10[j] + wx1 * v11[j]);
+      }
+      LaneVec<T>::store(out + ((size_t)b * HWo + p) * ldo + slot * N, v);
+    }
+    if (partial) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < N; j += 4) {
+        s1 += (v[j] + v[j + 1]) + (v[j + 2] + v[j + 3]);
+        s2 += (v[j] * v[j] + v[j + 1] * v[j + 1]) + (v[j + 2] * v[j + 2] + v[j + 3] * v[j + 3]);
+      }
+      a1 += (double)s1; a2 += (double)s2;
+    }
+  }
+  if (!partial) return;
+  for (int i = tid; i < 64; i += 256) reinterpret_cast<double*>(red)[i] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1)
+    if (off < gl || off >= CL) { a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); }   // (uniform condition)
+  const int wslot = (wave * 64 + lane) % CL;            // this lane's channel slot; a wave holds min(CL, 64) distinct slots
+  if ((wslot % gl) == 0 && lane < CL) { red[wave][wslot / gl][0] = a1; red[wave][wslot / gl][1] = a2; }
+  __syncthreads();
+  if (tid < G) {
+    double* o = partial + (((size_t)b * splits + sp) * G + tid) * 2;
+    o[0] = (red[0][tid][0] + red[1][tid][0]) + (red[2][tid][0] + red[3][tid][0]);
+    o[1] = (red[0][tid][1] + red[1][tid][1]) + (red[2][tid][1] + red[3][tid][1]);
+  }
+}
+
 __global__ void adaptive_avgpool_k(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int B,
                                    int H, int W, int C4, int S) {
   const int64_t total = (int64_t)B * S * S * C4;
@@ -352,7 +455,8 @@ __global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_k(const f
 // gnp != null (the head's mix, C = 64): also emits the GroupNorm(8) partial sums of the OUTPUT, one (sum, sum of squares) per
 // (sample, block, group) at gnp[((b * blocks_per_image + block) * 8 + group) * 2] -- the statistics pass over the mixed tensor
 // (one more read of 537 MB at 512 x 512, B = 8) disappears; gn_finalize folds the slots in a fixed order.
-template <int BS, bool PC, bool O16, bool MIX = false>
+// IO16 (bf16 activation stream, the head's mix): `in` and `out` are bf16 tensors.
+template <int BS, bool PC, bool O16, bool MIX = false, bool IO16 = false>
 __global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_fast_k(const float* __restrict__ in, int ldi, float* __restrict__ out,
                                                                              int ldo, int B, int H, int W, int C,
                                                                              const float* __restrict__ mats, __bf16* __restrict__ o16,
@@ -377,7 +481,8 @@ __global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_fast_k(co
 #pragma unroll
     for (int u = 0; u < BS; ++u)
 #pragma unroll
-      for (int v = 0; v < BS; ++v) X[u][v] = in[(base + (size_t)u * W + v) * ldi + c];
+      for (int v = 0; v < BS; ++v)
+        X[u][v] = IO16 ? (float)reinterpret_cast<const __bf16*>(in)[(base + (size_t)u * W + v) * ldi + c] : in[(base + (size_t)u * W + v) * ldi + c];
     float tmp[BS][BS];
 #pragma unroll
     for (int u = 0; u < BS; ++u) {
@@ -404,7 +509,8 @@ __global__ __launch_bounds__(BS == 8 ? 128 : 256) void block_transform_fast_k(co
         for (int k = 0; k < BS; ++k) a = fmaf(tmp[u][k], tr[k], a);
         const size_t o = base + (size_t)u * W + v;
         if (MIX) a = mix_in * X[u][v] + mix_t * a;       // the head's u5 + 0.1 DCT(u5) (webp_inference.py:396)
-        out[o * ldo + c] = a;
+        if (IO16) { const __bf16 h = (__bf16)a; reinterpret_cast<__bf16*>(out)[o * ldo + c] = h; a = (float)h; }   // (sums of what is stored)
+        else out[o * ldo + c] = a;
         if (O16) o16[o * C + c] = (__bf16)a;
         if (MIX) { gs1 += a; gs2 = fmaf(a, a, gs2); }
       }
@@ -638,6 +744,55 @@ void launch_upsample2(const float* in, int ldi, float* out, int ldo, int B, int 
   launch_bilinear(in, ldi, out, ldo, B, H, W, 2 * H, 2 * W, C, 0.5f, 0.5f, 0, 1.0f, s);
 }
 
+// pool / upsample / statistics passes of the inter-block stream (stream_k): returns the number of splits per sample the partial
+// sums were written with (what launch_gn_from_partials needs), 0 without statistics
+namespace {
+template <int MODE, typename T>
+int launch_stream(const void* in, int ldi, void* out, int ldo, int B, int Hi, int Wi, int C, int G, double* partial, hipStream_t s) {
+  constexpr int N = LaneVec<T>::N;
+  const int CL = C / N;
+  const bool pow2 = CL > 0 && (CL & (CL - 1)) == 0;
+  if ((C % N) != 0 || !pow2 || CL > 256 || (ldi % N) != 0 || (MODE != S16_STATS && (ldo % N) != 0) || (MODE == S16_POOL && ((Hi | Wi) & 1)))
+    throw std::runtime_error("stream pass: channel count must be 16 bytes * 2^k (at most 256 lanes per pixel) with 16-byte aligned rows");
+  int gl = 1;
+  if (partial) {
+    if (!stream_stats_supported(C, G, (int)sizeof(T))) throw std::runtime_error("stream pass: a group must be 16 bytes * 2^k of channels, at most 8 groups");
+    gl = C / G / N;
+  }
+  const int Ho = MODE == S16_POOL ? Hi / 2 : MODE == S16_UP ? 2 * Hi : Hi, Wo = MODE == S16_POOL ? Wi / 2 : MODE == S16_UP ? 2 * Wi : Wi;
+  const int ppi = 256 / CL;
+  int splits = cdiv(Ho * Wo, ppi * 4);
+  splits = splits < 1 ? 1 : (splits > GN_MAX_SPLITS ? GN_MAX_SPLITS : splits);
+  if (Ho * Wo <= 0 || B <= 0) return 0;
+  hipLaunchKernelGGL((stream_k<MODE, T>), dim3(splits, B), dim3(256), 0, s, reinterpret_cast<const T*>(in), ldi, reinterpret_cast<T*>(out), ldo,
+                     Hi, Wi, CL, gl, G, splits, FastDiv((unsigned)Wo), partial);
+  DDPMIR_HIP_CHECK(hipGetLastError());
+  return partial ? splits : 0;
+}
+}  // namespace
+
+bool stream_stats_supported(int C, int G, int elem_bytes) {
+  const int N = 16 / elem_bytes;
+  if (G < 1 || G > 8 || (C % G) != 0 || ((C / G) % N) != 0 || (C % N) != 0) return false;
+  const int gl = C / G / N, CL = C / N;
+  return (gl & (gl - 1)) == 0 && (CL & (CL - 1)) == 0 && CL <= 256;
+}
+int launch_stats16(const void* x16, int ldx, int B, int H, int W, int C, int G, double* partial, hipStream_t s) {
+  return launch_stream<S16_STATS, __bf16>(x16, ldx, nullptr, 0, B, H, W, C, G, partial, s);
+}
+int launch_maxpool2_16(const void* in16, int ldi, void* out16, int ldo, int B, int H, int W, int C, hipStream_t s, double* partial, int G) {
+  return launch_stream<S16_POOL, __bf16>(in16, ldi, out16, ldo, B, H, W, C, G, partial, s);
+}
+int launch_upsample2_16(const void* in16, int ldi, void* out16, int ldo, int B, int H, int W, int C, hipStream_t s, double* partial, int G) {
+  return launch_stream<S16_UP, __bf16>(in16, ldi, out16, ldo, B, H, W, C, G, partial, s);
+}
+int launch_maxpool2_stats(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, hipStream_t s, double* partial, int G) {
+  return launch_stream<S16_POOL, float>(in, ldi, out, ldo, B, H, W, C, G, partial, s);
+}
+int launch_upsample2_stats(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, hipStream_t s, double* partial, int G) {
+  return launch_stream<S16_UP, float>(in, ldi, out, ldo, B, H, W, C, G, partial, s);
+}
+
 void launch_adaptive_avgpool(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int S,
                              hipStream_t s) {
   int64_t total = (int64_t)B * S * S * (C / 4);
@@ -661,8 +816,10 @@ void launch_pool_from8(const float* sums, float* out, int ldo, int B, int H, int
 
 void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int bs,
                             const float* mats, int per_channel, float mix_in, float mix_t, hipStream_t s,
-                            void* low16, void* high16, int low, double* gn_partial_out) {
+                            void* low16, void* high16, int low, double* gn_partial_out, int io16) {
   int64_t total = (int64_t)B * cdiv(H, bs) * cdiv(W, bs) * C;
+  if (io16 && !((H % bs) == 0 && (W % bs) == 0 && !high16 && !low16 && !per_channel && (bs == 4 || bs == 8) && !(mix_in == 0.f && mix_t == 1.f)))
+    throw std::runtime_error("block transform: bf16 in / out is the head's mixed transform on whole blocks only");
   __bf16* l16 = reinterpret_cast<__bf16*>(low16);
   __bf16* h16 = reinterpret_cast<__bf16*>(high16);
   if ((H % bs) == 0 && (W % bs) == 0 && !h16 && (bs == 4 || bs == 8)) {
@@ -673,7 +830,8 @@ void launch_block_transform(const float* in, int ldi, float* out, int ldo, int B
     if (gn_partial_out && (C != 64 || mix_in == 0.f)) throw std::runtime_error("block transform: fused GroupNorm sums need the 64-channel mixed output");
     if (!(mix_in == 0.f && mix_t == 1.f)) {   // mixed output: the model's head only (shared matrix, no bf16 copy)
       if (per_channel || l16) goto general;
-      if (bs == 4) go(block_transform_fast_k<4, false, false, true>, 256);
+      if (io16) { if (bs == 4) go(block_transform_fast_k<4, false, false, true, true>, 256); else go(block_transform_fast_k<8, false, false, true, true>, 128); }
+      else if (bs == 4) go(block_transform_fast_k<4, false, false, true>, 256);
       else go(block_transform_fast_k<8, false, false, true>, 128);
     } else if (bs == 4) {
       if (per_channel) { if (l16) go(block_transform_fast_k<4, true, true>, 256); else go(block_transform_fast_k<4, true, false>, 256); }
@@ -701,9 +859,10 @@ general:
 bool block_transform_gn_fusable(int H, int W, int C, int bs) { return C == 64 && (bs == 4 || bs == 8) && (H % bs) == 0 && (W % bs) == 0; }
 
 void launch_gn_from_partials(const double* partial, int splits, int B, double n_per_group, int C, int G, const float* gamma,
-                             const float* beta, float* scale, float* shift, hipStream_t stream) {
-  hipLaunchKernelGGL(gn_finalize, dim3(G, B), dim3(256), 0, stream, partial, splits, n_per_group, C, round_up(C, 4), G, gamma, beta,
-                     scale, shift, round_up(C, 4));
+                             const float* beta, float* scale, float* shift, hipStream_t stream, int ldsc, int zero_to) {
+  const int Cs = ldsc > 0 ? ldsc : round_up(C, 4);
+  hipLaunchKernelGGL(gn_finalize, dim3(G, B), dim3(256), 0, stream, partial, splits, n_per_group, C, Cs, G, gamma, beta,
+                     scale, shift, ldsc > 0 ? (zero_to < 0 ? 0 : zero_to) : Cs);
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

@@ -30,6 +30,7 @@ _sigs = {
                                             _P, _P, _P]),
     "ddpmir_op_maxpool2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ddpmir_op_upsample2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ddpmir_op_stream16": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int]),
     "ddpmir_op_bilinear": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ddpmir_op_adaptive_avgpool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ddpmir_op_time_embed": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
@@ -212,6 +213,21 @@ def upsample2(x):
     out = np.empty((b, 2 * h, 2 * w, c), np.float32)
     _chk(lib, lib.ddpmir_op_upsample2(_p(x), b, h, w, c, _p(out)), "op_upsample2")
     return out
+
+
+def stream16(mode, x, groups=0, gamma=None, beta=None, f32=False):
+    """inter-block stream pass on NHWC x (f32=False: the bf16 stream, x rounded to bf16 inside): mode 0 statistics, 1 max-pool 2x2, 2 bilinear x2.
+    Returns (out or None, scale, shift) -- scale / shift [B, C] are the GroupNorm affine of the produced tensor (groups > 0)."""
+    lib = _lib_ops()
+    x = _f(x)
+    b, h, w, c = x.shape
+    ho, wo = (h // 2, w // 2) if mode == 1 else (2 * h, 2 * w) if mode == 2 else (h, w)
+    out = np.empty((b, ho, wo, c), np.float32)
+    sc, sh = np.empty((b, c), np.float32), np.empty((b, c), np.float32)
+    g = _f(gamma) if gamma is not None else np.ones(c, np.float32)
+    be = _f(beta) if beta is not None else np.zeros(c, np.float32)
+    _chk(lib, lib.ddpmir_op_stream16(int(mode), _p(x), b, h, w, c, c, int(groups), _p(g), _p(be), _p(out), _p(sc), _p(sh), int(bool(f32))), "op_stream16")
+    return (out if mode else None), sc, sh
 
 
 def bilinear(x, ho, wo):

@@ -155,7 +155,15 @@ const char* ddpmir_version(void);
 /* Tuning / diagnostic options of a context.  "attention_no_max_bound" (default 80, log2 units): a block of queries runs in
  * the attention kernel WITHOUT a running softmax maximum when max|q| of the block * max|k| of its (batch, head) pair stays
  * below it (scores then cannot leave fp32's range); a negative value forces the general kernel everywhere (the worst case
- * bench.py reports as general_kernel_only). */
+ * bench.py reports as general_kernel_only).
+ * "fp8_min_channels" (64 / 128 / 256, default 256; DDPMIR_FP8, before the weights are loaded): the 3x3 convs with at least that
+ * many input and output channels take e4m3 operands.
+ * "bf16_activation_stream" (-1 / 0 / 1): the tensors BETWEEN residual blocks (block outputs, pooled / upsampled tensors, concat
+ * buffers) are stored as bf16 instead of fp32 -- the rounding the reference's own autocast applies to every conv output.
+ * -1 (default): in DDPMIR_FP8 mode only, whose error budget e4m3 dominates; 1: in DDPMIR_BF16 mode too (measured: forward error
+ * against the fp32 oracle mean 2.0e-3 instead of 1.7e-3 at 256 x 256; restored PSNR against fp32 mode over 64 images
+ * +0.0031 +- 0.0018 dB instead of +0.0034 +- 0.0016, i.e. unchanged; -7 % time at 512 x 512); 0: never.  AVIF and DDPMIR_F32
+ * always keep fp32. */
 int ddpmir_set_option(ddpmir_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus

@@ -75,6 +75,13 @@ int ddpmir_op_freq_gates_bf16(const float* x, int B, int H, int W, int C, int bs
 int ddpmir_op_maxpool2(const float* x, int B, int H, int W, int C, float* out);        /* webp_inference.py:342 */
 int ddpmir_op_upsample2(const float* x, int B, int H, int W, int C, float* out);       /* webp_inference.py:389 */
 int ddpmir_op_bilinear(const float* x, int B, int Hi, int Wi, int C, int Ho, int Wo, float* out);
+/* The passes between residual blocks in bf16 / fp8 mode: mode 0 statistics alone, 1 max-pool 2x2 (webp_inference.py:342),
+ * 2 bilinear x2 (:389) on NHWC tensors; with G > 0 the pass also leaves GroupNorm partial sums of what it produced, returned
+ * here folded into scale / shift [B][C] (webp_inference.py:277-279).  f32 = 0: the bf16 activation stream (x is rounded to bf16
+ * on the way in, rows ldx >= C elements apart; out = the bf16 result widened to fp32 -- the rounding the reference's autocast
+ * applies to conv outputs); f32 = 1: fp32 tensors (modes 1, 2) */
+int ddpmir_op_stream16(int mode, const float* x, int B, int H, int W, int C, int ldx, int G, const float* gamma, const float* beta,
+                       float* out, float* scale, float* shift, int f32);
 int ddpmir_op_adaptive_avgpool(const float* x, int B, int H, int W, int C, int S, float* out);
 
 /* TimeEmbedding.forward (webp_inference.py:145-151): t [B] -> temb [B,256] */

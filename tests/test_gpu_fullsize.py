@@ -98,6 +98,31 @@ def test_full_size_host_codec_loop_properties(arch, codec_kind, steps, models):
     assert float(e.max()) < 2e-2 and float(e.mean()) < 2e-3, (float(e.max()), float(e.mean()))
 
 
+def test_bf16_activation_stream_option(models):
+    """Option "bf16_activation_stream" = 1: bf16 mode stores what flows between residual blocks as bf16 too (fp8 mode's
+    default; the rounding the reference's autocast applies to every conv output).  It is an opt-in because it costs margin
+    against the fp32 oracle -- forward error mean 2.0e-3 instead of 1.7e-3 at 256 x 256 (restored PSNR over 64 images is
+    unchanged: +0.0031 +- 0.0018 dB vs +0.0034 +- 0.0016 against fp32 mode, profiles/r03_psnr256_bias.txt) -- so its fence is
+    wider than bf16 mode's (max 2.5e-2, mean 2.5e-3 against the oracle fixtures) and bf16 mode's default stays fp32.  Also: switching the option re-plans, results are deterministic, 0 restores the default bit for bit."""
+    import torch
+    for name, arch, attn in (("jpeg_fwd256_oracle", spec.ARCH_JPEG, "all"), ("jpeg_fwd512_bott_oracle", spec.ARCH_JPEG, "bottleneck")):
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        s = int(g["stride"]) if "stride" in g.files else 1
+        x = tt(synth.synth_images(1, g["y"].shape[-1] * s, seed=int(g["seed_x"])))
+        m = models(arch, attn_levels=attn, dtype="bf16")
+        y0 = m(x, tt(g["t"]), tt(g["cl"]))
+        m.set_option("bf16_activation_stream", 1)
+        y1 = m(x, tt(g["t"]), tt(g["cl"]))
+        assert torch.equal(m(x, tt(g["t"]), tt(g["cl"])), y1)
+        e0 = np.abs(y0.cpu().numpy()[:, :, ::s, ::s] - g["y"])
+        e1 = np.abs(y1.cpu().numpy()[:, :, ::s, ::s] - g["y"])
+        print(f"{name}: bf16 mode fp32 stream max {e0.max():.2e} mean {e0.mean():.2e}; bf16 stream max {e1.max():.2e} mean {e1.mean():.2e}")
+        assert not torch.equal(y0, y1)
+        assert e1.max() < 2.5e-2 and e1.mean() < 2.5e-3, (e1.max(), e1.mean())
+        m.set_option("bf16_activation_stream", -1)
+        assert torch.equal(m(x, tt(g["t"]), tt(g["cl"])), y0)
+
+
 def test_fp8_mode_configs4(models):
     """BASELINE configs[4]: 512 x 512, attention at the bottleneck only, "fp8 MFMA": DDPMIR_FP8 = bf16 mode with OCP e4m3
     operands (per-tensor power-of-two weight scale, unit activation scale) in the 3x3 convolutions with >= 256 input and

@@ -334,6 +334,50 @@ def test_pool_and_resample(ops):
     close(nchw(ops.bilinear(nhwc(a8), 12, 20)), O.bilinear(a8, 12, 20), 1e-6)
 
 
+def test_bf16_activation_stream_passes(ops):
+    """bf16 / fp8 mode: what flows between residual blocks is bf16 (as under the reference's autocast), and the max-pool /
+    bilinear x2 passes also leave the GroupNorm sums of what they wrote.  Max-pool of bf16 values is exact; bilinear x2 equals the
+    oracle's interpolation of the rounded input rounded once more; the folded scale / shift equal GroupNorm statistics of the
+    produced bf16 tensor (oracle group_norm: webp_inference.py:277-279)."""
+    def bf16(a):
+        u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+
+    def affine(t_nchw, G, gamma, beta):   # per (b, c) scale / shift such that group_norm(t) = t * scale + shift
+        B, C = t_nchw.shape[:2]
+        g = t_nchw.astype(np.float64).reshape(B, G, -1)
+        mean, var = g.mean(-1), g.var(-1)
+        rstd = 1.0 / np.sqrt(var + 1e-5)
+        sc = np.repeat(rstd, C // G, axis=1) * gamma[None]
+        sh = beta[None] - np.repeat(mean, C // G, axis=1) * sc
+        return sc, sh
+    for (B, C, H, W, G) in ((2, 64, 16, 24, 8), (3, 128, 8, 8, 8), (1, 512, 4, 6, 4), (2, 1024, 2, 2, 8), (2, 64, 64, 32, 4)):
+        x = rnd(B, C, H, W, seed=40 + C, scale=1.5) + 0.3
+        xr = bf16(x)
+        gamma, beta = rnd(C, seed=41) * 0.2 + 1.0, rnd(C, seed=42) * 0.1
+        for mode, ref in ((0, xr), (1, O.max_pool2(xr)), (2, bf16(O.upsample2(xr)))):
+            out, sc, sh = ops.stream16(mode, nhwc(x), G, gamma, beta)
+            if mode == 1:
+                assert np.array_equal(nchw(out), ref)
+            elif mode == 2:   # fp32 interpolation order differs from numpy's in the last bit: at most one bf16 ulp
+                d = np.abs(nchw(out) - ref)
+                assert d.max() <= np.abs(ref).max() * 2.0 ** -7 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())
+                ref = nchw(out)   # statistics are those of the tensor the pass wrote
+            esc, esh = affine(ref, G, gamma.astype(np.float64), beta.astype(np.float64))
+            close(sc, esc, 2e-5)
+            close(sh, esh, 2e-5)
+        # the fp32 stream (bf16 mode's default): same passes on fp32 tensors, statistics of the fp32 result
+        for mode, ref in ((1, O.max_pool2(x)), (2, O.upsample2(x))):
+            out, sc, sh = ops.stream16(mode, nhwc(x), G, gamma, beta, f32=True)
+            if mode == 1:
+                assert np.array_equal(nchw(out), ref)
+            else:
+                close(nchw(out), ref, 1e-6)
+            esc, esh = affine(nchw(out), G, gamma.astype(np.float64), beta.astype(np.float64))
+            close(sc, esc, 2e-5)
+            close(sh, esh, 2e-5)
+
+
 def test_time_embedding(ops, synth_state):
     sd = synth_state(0)
     t = np.array([0.0, 0.37, 0.999, 0.5], np.float32)

@@ -1,12 +1,14 @@
-"""Ordered per-dispatch listing of ONE U-Net forward from a rocprofv3 kernel trace (the last complete forward of the run:
-the dispatches between the last two nchw3_to_nhwc4 kernels), with the idle gap before each dispatch.
+"""Ordered per-dispatch listing of ONE U-Net forward from a rocprofv3 kernel trace (the middle forward of the run, i.e. one of
+bench.py's timed steps: the dispatches between two consecutive nchw3_to_nhwc4 kernels), with the idle gap before each dispatch.
+(Not the last forward: for the bottleneck-attention workloads that one belongs to the untimed GEMM-class pass, whose per-launch
+HIP event records put ~5 us before and after every GEMM launch.)
 usage: python tools/forward_timeline.py <rocprofv3 output dir> > profiles/rNN_forward_timeline.txt"""
 import csv, glob, os, sys
 d = sys.argv[1]
 t = max(glob.glob(d + "/*/*kernel_trace.csv"), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(t)), key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "nchw3_to_nhwc4" in r["Kernel_Name"]]
-a, b = starts[-2], starts[-1]
+a, b = starts[len(starts) // 2 - 1], starts[len(starts) // 2]
 fwd = rows[a:b]
 t0 = int(fwd[0]["Start_Timestamp"])
 prev_end = t0

@@ -46,7 +46,7 @@ int main() {
       if (rep) printf("%-64s %7.2f us per launch beyond the 20 us spin\n", what, ms * 1e3 / N - 20.0);
     }
   };
-  const dim3 g(1024), t(256);
+  const dim3 g(256), t(256);   // one workgroup per CU: every variant is resident at once
   run("plain, no LDS", [&](int) { hipLaunchKernelGGL(k_plain, g, t, 0, s, o, C); });
   run("dynamic LDS 1 KiB", [&](int) { hipLaunchKernelGGL(k_dyn, g, t, 1024, s, o, C); });
   run("dynamic LDS 48 KiB", [&](int) { hipLaunchKernelGGL(k_dyn, g, t, 48 * 1024, s, o, C); });
