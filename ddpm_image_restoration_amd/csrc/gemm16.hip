@@ -409,13 +409,17 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
   // b rows: nt*32 + lr -> the key only depends on lr because 32 is a multiple of (CPR << RSH)
   const int a_key = (arow >> RSH) & (CPR - 1), b_key = (lr >> RSH) & (CPR - 1);
 
-  constexpr int AHEAD = STAGES - 1;                     // stages in flight: 2 (3-stage ring) or 1 (2-stage ring)
-  if (nit > 0) issue(0);
-  if (AHEAD > 1 && nit > 1) issue(1);
+  constexpr int AHEAD = STAGES - 1;                     // stages in flight: STAGES - 1
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i)
+    if (i < nit) issue(i);
   for (int it = 0; it < nit; ++it) {
-    // stage `it` has landed once at most AHEAD-1 younger stages of THIS wave are still in flight; the barrier extends
-    // that to every wave's share and also retires everybody's reads of the buffer that is refilled next
-    if (AHEAD > 1 && it + 1 < nit) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    // stage `it` has landed once at most the younger stages of THIS wave are still in flight (AHEAD - 1 of them, fewer at the
+    // end of the loop); the barrier extends that to every wave's share and also retires everybody's reads of the buffer
+    // that is refilled next
+    const int younger = nit - 1 - it < AHEAD - 1 ? nit - 1 - it : AHEAD - 1;
+    if (AHEAD > 2 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+    else if (AHEAD > 1 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (it + AHEAD < nit) issue(it + AHEAD);
@@ -1198,6 +1202,13 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
       return;
     }
   }
+#ifdef DDPMIR_EXPERIMENTS
+  if constexpr (NT == 4) {   // deeper DMA rings at BK = 32 (tools/ab_switches.py): 3 stages / 3 workgroups per CU, 4 stages / 2
+    const int sel = exp_value("DDPMIR_GEMM_RING");   // 3 or 4: every 128-column launch; 13 / 14: only where BK = 64 is chosen today
+    if (sel == 3 || (sel == 13 && bk64)) { launch_nt<NT, 32, 3>(p, M, stream); return; }
+    if (sel == 4 || (sel == 14 && bk64)) { launch_nt<NT, 32, 4>(p, M, stream); return; }
+  }
+#endif
   if (bk64) launch_nt<NT, 64, 2>(p, M, stream);
   else launch_nt<NT, 32, 2>(p, M, stream);
 }

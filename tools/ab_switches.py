@@ -1,5 +1,5 @@
 """A/B of experiment switches (experiments build, DDPMIR_LIB_PATH) on ONE device: bench slices in interleaved child processes.
-usage: ab_switches.py "SW1,SW2+SW3,..." [c5|head|both] [rounds]   ('' = no switch; SW2+SW3 = both set)"""
+usage: ab_switches.py "SW1,SW2+SW3,SW4=3,..." [c5|head|both] [rounds]   ('' = no switch; SW2+SW3 = both set; SW=value)"""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sets = [s for s in sys.argv[1].split(",")]
@@ -14,7 +14,8 @@ for rnd in range(rounds):
         for s in sets:
             env = dict(os.environ, DDPMIR_LIB_PATH=os.path.join(root, "ddpm_image_restoration_amd", "libddpmir_exp.so"))
             for v in [x for x in s.split("+") if x]:
-                env[v] = "1"
+                k, _, val = v.partition("=")       # SW or SW=value
+                env[k] = val or "1"
             out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-workloads"] + WL[w], env=env, capture_output=True, text=True, cwd=root)
             try:
                 d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
