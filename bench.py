@@ -219,7 +219,9 @@ def run_workload(w: dict, env, dev, K: int, W: int, full: bool = False, graph: i
                            "frac_of_bf16_peak": tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"]}
     if roof is None and gemm is not None:
         # attention at the bottleneck only: the GEMM launches are the dominant kernel class of the timestep
-        traffic, tsrc = committed_traffic(f"{arch_name}_{dtype}_{R}_B{B}_{attn}", lib_src_hash(det["version"]))
+        fmc, s16 = w.get("fp8_min_channels"), w.get("stream16")
+        variant = dtype + ("@%d" % fmc if fmc not in (None, 256) else "") + ("+stream16" if s16 == 1 else "")
+        traffic, tsrc = committed_traffic(f"{arch_name}_{variant}_{R}_B{B}_{attn}", lib_src_hash(det["version"]))
         roof = {"bound": "mfma", "kernel": "GEMM class: all %d launches per forward of the DMA-streamed implicit-GEMM kernels (3x3 / 1x1 convolutions, "
                                            "projections; gemm16_kernel / conv3x3_strip_kernel / splitk_reduce_k)" % round(gemm["launches_per_forward"]),
                 "achieved": gemm["all"]["achieved"], "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": gemm["all"]["frac_of_bf16_peak"],
