@@ -20,6 +20,16 @@ def test_two_rank_job_reproduces_the_single_process_result():
 
 
 @pytest.mark.gpu
+def test_rccl_loopback():
+    """RCCL itself, as far as one GPU allows: a world-size-1 "nccl" process group runs every collective of dist.py with its
+    dtypes and shapes (tests/rccl_loopback_worker.py).  The multi-GPU curve is the driver's to measure."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_loopback_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "RCCL-LOOPBACK-OK" in r.stdout
+
+
+@pytest.mark.gpu
 def test_bench_contract_two_ranks():
     """bench.py under the driver's launch line (2 ranks): one JSON line from rank 0, whole-job value, no cpu_baseline."""
     import json
