@@ -437,6 +437,29 @@ def test_builtin_host_codec_pool_equals_pillow_callback_in_the_loop(name, arch, 
         assert torch.equal(a, b), (name, q)
 
 
+def test_bf16_activation_stream_in_the_two_lane_loop(models):
+    """fp8 mode's default and bf16 mode's option: the tensors between residual blocks are bf16.  Inside the two-lane host-codec
+    loop (WebP: down1 / up5 run per lane on row ranges of the concat buffers, the levels below once for both lanes) the row
+    offsets are taken in bf16 elements: x_theta of a timestep of the T=50 schedule stays within the mode's fence of fp32
+    mode's x_theta on the same x_t (a wrong offset would put another image's rows under a lane)."""
+    import torch
+    from ddpm_image_restoration_amd.sampler import DDRMWebPSampler
+    y = tt(O.compress(synth.synth_images(4, 64, seed=71), 10, "webp"))
+    kw = dict(steps=50, start_step=40, num_steps=1, seed=5, trace=True)
+    _, t32 = DDRMWebPSampler(models(spec.ARCH_WEBP)).sample(y, 10, **kw)
+    for dtype in ("bf16", "fp8"):
+        m = models(spec.ARCH_WEBP, dtype=dtype)
+        if dtype == "bf16":
+            m.set_option("bf16_activation_stream", 1)
+        _, t16 = DDRMWebPSampler(m).sample(y, 10, **kw)
+        assert torch.isfinite(t16).all()
+        e = (t16[0, 0] - t32[0, 0]).abs()
+        lim = (2.5e-2, 2.5e-3) if dtype == "bf16" else (0.17, 1.1e-2)
+        assert float(e.max()) < lim[0] and float(e.mean()) < lim[1], (dtype, float(e.max()), float(e.mean()))
+        if dtype == "bf16":
+            m.set_option("bf16_activation_stream", -1)
+
+
 def test_avif_per_image_jpeg_fallback_in_the_builtin_pool(models, monkeypatch):
     """avif_inference.py:88-95: an image whose AVIF round trip raises is silently round-tripped as JPEG instead (Pillow's plain
     save(format="JPEG", quality=q): 4:2:0 at every quality).  The built-in libavif pool keeps that behaviour per image: the
