@@ -384,10 +384,9 @@ void Context::layout_plan(Arena& a, int B, int H, int W) {
   p.bb1 = act((size_t)B * hw(5), 1024);
   p.bb2 = act((size_t)B * hw(5), 512);
   const int u_c[5] = {64, 64, 128, 256, 512};                  // up-block output channels at level 0..4
-  for (int l = 1; l < 5; ++l) p.u[l] = act((size_t)B * hw(l), u_c[l]);
-  // (up5's output stays fp32: the head's blockwise transform maps a thread to a channel, and its 2-byte accesses on a bf16
-  // tensor ran 4x slower than the 4-byte ones -- 0.98 vs 0.24 ms at 512 x 512, B = 8)
-  p.u[0].p = a.take<float>((size_t)B * hw(0) * u_c[0]); p.u[0].ld = u_c[0]; p.u[0].h = false;
+  for (int l = 0; l < 5; ++l) p.u[l] = act((size_t)B * hw(l), u_c[l]);
+  // (up5's output joins the bf16 stream too: the head's mixed transform goes through an LDS tile with 16-byte I/O, head_mix16_k;
+  //  a thread-per-channel pass with 2-byte global accesses ran 4x slower than its fp32 twin)
   // per-block scratch: max over blocks of pixels*cout is at level 0 (64 ch); deeper levels never exceed it
   size_t mc = 0;
   for (auto& d : kBlocks) mc = std::max(mc, (size_t)B * hw(d.level) * d.cout);
