@@ -754,6 +754,27 @@ def test_large_nonsquare_forward_bf16_tracks_fp32(name, arch, models):
     assert torch.equal(y1, y32[1:])
 
 
+@pytest.mark.parametrize("name,arch", [("webp", spec.ARCH_WEBP), ("jpeg", spec.ARCH_JPEG)])
+def test_nonsquare_forward_with_the_bf16_activation_stream(name, arch, models):
+    """The bf16 activation stream (fp8 mode's default, bf16 mode's option) on non-square sizes, rows of unequal length at every
+    level, both block sizes of the head's mixed transform (WebP 4, JPEG 8): the pool / bilinear / statistics passes and the
+    LDS-staged head transform take H and W separately.  Against the exact-fp32 path of the same library, within each mode's
+    fence; attention at the bottleneck only (what fp8 mode is specified for, and the level-0 tensors are the large ones)."""
+    import torch
+    for (H, W) in ((96, 160), (224, 64)):
+        x = synth.synth_images(2, max(H, W), seed=73)[:, :, :H, :W].copy()
+        t = np.array([0.6, 0.3], np.float32)
+        y32 = models(arch, attn_levels="bottleneck")(tt(x), tt(t), tt(t))
+        m16 = models(arch, attn_levels="bottleneck", dtype="bf16")
+        m16.set_option("bf16_activation_stream", 1)
+        e16 = (m16(tt(x), tt(t), tt(t)) - y32).abs()
+        m16.set_option("bf16_activation_stream", -1)
+        e8 = (models(arch, attn_levels="bottleneck", dtype="fp8")(tt(x), tt(t), tt(t)) - y32).abs()
+        print(f"{name} {H}x{W}: bf16 stream max {float(e16.max()):.2e} mean {float(e16.mean()):.2e}; fp8 max {float(e8.max()):.2e} mean {float(e8.mean()):.2e}")
+        assert float(e16.max()) < 2.5e-2 and float(e16.mean()) < 2.5e-3, (H, W, float(e16.max()), float(e16.mean()))
+        assert float(e8.max()) < 0.17 and float(e8.mean()) < 1.1e-2, (H, W, float(e8.max()), float(e8.mean()))
+
+
 @pytest.mark.parametrize("name,arch", [("webp", spec.ARCH_WEBP), ("avif", spec.ARCH_AVIF)])
 def test_two_lane_loop_shares_the_levels_below_full_resolution(name, arch, models):
     """Host-codec families: the loop runs down1 / up5 per lane and everything below once for both lanes (model.hip fwd_head /
