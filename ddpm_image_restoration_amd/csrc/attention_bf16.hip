@@ -22,7 +22,8 @@
 //      (batch, head) pairs whose scores are provably bounded (attn_pair_bounds_k: max|q| * max|k| <= NM_BOUND in log2
 //      units); head_dim <= 64.  The general kernel skips those pairs.
 //  K/V stream through LDS in stages of several 32-key tiles, double buffered, filled by global_load_lds (the packed
-//  images are a linear copy), laid out so every LDS read is a linear 1 KiB wave read (conflict-free).  Workgroups of one
+//  images are a linear copy), laid out so every LDS read is a linear 1 KiB wave read (conflict-free; the one exception is the
+//  V^T slab read at head_dim 16, 2-way on purpose: vt_row below).  Workgroups of one
 //  (batch, head) are placed on one XCD so the 4 MiB of K/V they all re-read stay in that XCD's L2.
 #include <cstdlib>
 #include <stdexcept>
@@ -141,15 +142,17 @@ __device__ __forceinline__ bool block_is_bounded(const PairBounds* bounds, const
   return sqrtf(q2) * 1.002f * km <= nm_bound;
 }
 
-// Row of the V^T slab a lane reads as its A-operand row.  Rows 0 .. D-1 are V^T, row D the ones row (head_dim <= 16).
-// head_dim 16: ds_read_b128 is served in the lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} (+32): the ones row sits one
-// 256-byte bank row above row 0, so with lanes 16-31 ALL on it the first group holds rows 0-3 and row 16 on the same banks
-// (2-way: SQ_LDS_BANK_CONFLICT was 25 % of the LDS cycles of this kernel).  Only A row 16 must be the ones row (rows 17-31
-// of O^T are never read), so lanes 17-31 re-read rows 1-15: every group then covers 16 distinct 16-byte slots.
+// Row of the V^T slab a lane reads as its A-operand row.  Rows 0 .. D-1 are V^T, row D the ones row (head_dim <= 16): lanes
+// D .. 31 ALL read the ones row (only A row D must be it; rows D+1 .. 31 of O^T are never read).
+// head_dim 16: ds_read_b128 is served in the lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} (+32) and the ones row sits one
+// 256-byte bank row above row 0, so the first group holds rows 0-3 and row 16 on the same banks: 2-way, SQ_LDS_BANK_CONFLICT =
+// 25 % of this kernel's LDS cycles.  Round 3 removed that count by letting lanes 17-31 re-read rows 1-15 (every group 16 distinct
+// slots: conflicts 67.1 M -> 0) -- and a same-device A/B of the two builds (tools/attn_lib_ab.py, profiles/r03_attn_vrow_ab.txt)
+// showed the conflict-free pattern 2.2 % SLOWER per level-0 launch (25.61 vs 25.07 ms): fifteen lanes on one broadcast row cost
+// the LDS less than fifteen more distinct rows, and LDS is 8-10 % busy here anyway.  The counter is explained; the pattern stays.
 template <int D, bool ONES>
 __device__ __forceinline__ int vt_row(int lr) {
   if (!ONES) return lr;
-  if (D == 16) return lr <= 16 ? lr : lr - 16;
   return lr < D ? lr : D;
 }
 
