@@ -6,6 +6,8 @@ trees = {"r02 (a6e9c77)": os.path.join(root, ".ab_r2"), "r03 (HEAD)": root}
 WL = {"configs[1] JPEG 256^2 B=16": [],
       "configs[4] shape bf16": ["--size", "512", "--batch", "8", "--attn", "bottleneck", "--quality", "20"],
       "configs[4] shape fp8": ["--size", "512", "--batch", "8", "--attn", "bottleneck", "--quality", "20", "--dtype", "fp8"]}
+if len(sys.argv) > 1:   # e.g. "configs[1]": only the workloads whose name starts with it
+    WL = {k: v for k, v in WL.items() if k.startswith(sys.argv[1])}
 res = {}
 for rnd in range(2):
     for wname, wargs in WL.items():
