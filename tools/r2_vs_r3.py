@@ -1,5 +1,8 @@
 """Round 2's final tree (a copy under .ab_r2/, built from commit a6e9c77) against HEAD on ONE device: interleaved child processes of
-each tree's own bench.py.  usage: python tools/r2_vs_r3.py   (inside a gpurun call; .ab_r2/ is git-ignored)"""
+each tree's own bench.py.  usage: python tools/r2_vs_r3.py ["configs[1]"]   (inside a gpurun call; .ab_r2/ is git-ignored)
+.ab_r2/ is made with:  git worktree add /tmp/r2tree a6e9c77; mkdir .ab_r2; cp -r /tmp/r2tree/{ddpm_image_restoration_amd,bench.py,
+__graft_entry__.py,oracle,include,profiles} .ab_r2/; git worktree remove --force /tmp/r2tree; (cd .ab_r2 && python -c
+"from ddpm_image_restoration_amd import build; build.build(force=True)")   -- 50 s of hipcc; it travels to the GPU box with the snapshot."""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 trees = {"r02 (a6e9c77)": os.path.join(root, ".ab_r2"), "r03 (HEAD)": root}
