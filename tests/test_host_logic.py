@@ -119,3 +119,34 @@ def test_bench_reads_roofline_traffic_from_the_committed_profile():
 def test_packed_blob_header_fields():
     from ddpm_image_restoration_amd import model
     assert model.PACKED_MAGIC == b"DDPMIRW\x00" and len(model.PACKED_MAGIC) == 8
+
+
+def _build_and_run_host_check(tmp_path, source, marker):
+    """tests/c_abi/<source>: host code of csrc/common.h, compiled with hipcc (no GPU needed) and run here."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / source.replace(".cpp", ""))
+    r = subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", "-I", os.path.join(root, "ddpm_image_restoration_amd", "csrc"),
+                        os.path.join(root, "tests", "c_abi", source), "-o", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and marker in r.stdout, r.stdout[-500:]
+
+
+def test_fastdiv_magic_numbers_are_exact(tmp_path):
+    """csrc/common.h FastDiv: the magic-number division that turns a pixel index into (sample, row, column) in the GEMM, strip and
+    pointwise kernels must equal n / d for every n < 2^31: exhaustive for small n, around every multiple of d, 200 000 random n per
+    divisor, 39 divisors incl. every H*W / W / channel-slot count the models use."""
+    _build_and_run_host_check(tmp_path, "fastdiv_check.cpp", "FASTDIV-OK")
+
+
+def test_e4m3_weight_packer_rounds_to_nearest_even(tmp_path):
+    """csrc/common.h f32_to_e4m3 (fp8 mode's weight packer, host twin of v_cvt_pk_fp8_f32): equals the nearest OCP e4m3fn code by
+    brute force -- every code, every midpoint between neighbours and one ulp either side (ties to even), 400 000 random values
+    over 2^-12 .. 2^9, saturation at 448, infinities, NaN."""
+    _build_and_run_host_check(tmp_path, "e4m3_check.cpp", "E4M3-OK")
