@@ -150,3 +150,31 @@ def test_e4m3_weight_packer_rounds_to_nearest_even(tmp_path):
     brute force -- every code, every midpoint between neighbours and one ulp either side (ties to even), 400 000 random values
     over 2^-12 .. 2^9, saturation at 448, infinities, NaN."""
     _build_and_run_host_check(tmp_path, "e4m3_check.cpp", "E4M3-OK")
+
+
+def test_bf16_grade_gelu_formula():
+    """gemm16.hip gelu_bf16_grade (the GroupNorm-apply pass of bf16 / fp8 mode): erf by Abramowitz & Stegun 7.1.26 evaluated in
+    fp32.  Restated here in numpy fp32: absolute error against exact erf-GELU (webp_inference.py:313, nn.GELU()) below 5e-7 over
+    [-12, 12], and on unit-normal inputs (what GroupNorm hands it) fewer than 1 in 5000 bf16-rounded results differ from the
+    bf16-rounded exact value -- three orders below bf16's own rounding error."""
+    from scipy.special import erf
+    f = np.float32
+
+    def gelu16(v):
+        x = np.abs(v) * f(0.70710678118654752440)
+        t = (f(1) / (f(0.3275911) * x + f(1))).astype(np.float32)
+        poly = (t * (t * (t * (t * (t * f(1.061405429) + f(-1.453152027)) + f(1.421413741)) + f(-0.284496736)) + f(0.254829592))).astype(np.float32)
+        e = (f(1) - poly * np.exp(-x * x).astype(np.float32)).astype(np.float32)
+        return (f(0.5) * v * (f(1) + np.copysign(e, v))).astype(np.float32)
+
+    def exact(v):
+        return 0.5 * v.astype(np.float64) * (1 + erf(v.astype(np.float64) / np.sqrt(2)))
+
+    def bf16(a):
+        u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    v = np.linspace(-12, 12, 400001).astype(np.float32)
+    assert np.abs(gelu16(v) - exact(v)).max() < 5e-7
+    v = np.random.default_rng(0).standard_normal(1000000).astype(np.float32)
+    a, b = bf16(gelu16(v)), bf16(exact(v).astype(np.float32))
+    assert (a != b).mean() < 2e-4 and np.abs(a - b).mean() < 1e-3 * np.abs(b - exact(v)).mean()
