@@ -1,0 +1,342 @@
+// Round-4 groundwork, NOT product code: a 256 x 256 x 64 bf16 tile with eight waves, LDS-DMA half-tiles that stay in flight
+// across raw barriers (counted vmcnt, never 0 in the loop) and two wave groups staggered by one barrier, as a stand-alone
+// program with its own reference check -- the structure DESIGN.md 9 (a) names as the next step for the 3x3 convs with
+// Cout >= 256 (gemm16_kernel reaches 630-690 TFLOP/s there, the vendor GEMM 1.0-1.2 PFLOP/s on the plain equivalents:
+// profiles/r02_gemm_vendor_yardstick.txt).  Two operand modes: plain  C[M][N] = A[M][K] . W[N][K]^T  and the implicit 3x3
+// convolution over an NHWC tensor (K = 9 taps x Cin, channel chunk outer / tap inner, out-of-image taps from a zero page),
+// each with and without the stagger.
+//
+//   build: hipcc -O3 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form gemm256_stagger.hip -o gemm256_stagger
+//   run:   timeout -k 5 60 ./gemm256_stagger            (prints TFLOP/s, max error against a CPU reference on sampled rows,
+//                                                        and whether repeated launches are bit-identical = race screen)
+//
+// Geometry.  Workgroup = 512 threads = 8 waves as 2 (rows, wr) x 4 (columns, wc); a wave owns 128 x 64 of the tile = 4 x 2
+// accumulators of v_mfma_f32_32x32x16_bf16 (128 VGPRs).  A K tile (64 deep) is staged as FOUR half-tiles of 16 KiB, in the
+// order  B0, A0, B1, A1 :  A-half h = the rows {wr*128 + h*64 .. +63} of both wave rows, B-half h = the columns
+// {wc*64 + h*32 .. +31} of all four wave columns, so every wave finds its own sub-rows in every half.  The stream of half-tiles
+// g = 4 t + kind lives in slot g mod 8 of a 128 KiB ring.  A K tile is four phases, quadrant order (A0,B0) (A0,B1) (A1,B1)
+// (A1,B0); each phase reads ONE new register sub-tile from LDS (A: 8 ds_read_b128, B: 4; the B0 of the next tile is read in the
+// fourth phase into the B register set the third phase freed -- so the body is unrolled over two K tiles and every register
+// index is a compile-time constant), issues ONE half-tile (two DMA instructions per thread) five half-tiles ahead, and
+// runs 8 MFMAs.
+//
+// Synchronisation.  Phase = [reads + DMA issue] s_barrier [MFMAs, counted wait] s_barrier.  Group 1 (wr = 1) executes one
+// extra barrier before the loop (group 0 one after it), so while one group's MFMAs run the other group's LDS reads are served:
+// 24 KiB of LDS reads per group-phase = 192 LDS cycles beside 256 matrix-pipe cycles.  In barrier intervals: group 0 reads
+// phase ph in interval 2 ph, multiplies in 2 ph + 1; group 1 one interval later.
+//   RAW: half-tile g is issued in the read section of phase g - 5.  `s_waitcnt vmcnt(4)` at the end of the MFMA section of
+//   phase g - 3 (two younger half-tiles stay in flight) retires this wave's share; group 1 does so in interval 2 g - 4, so after
+//   barrier 2 g - 4 every share has landed; the first read of g is in phase g - 1 (B0 of the next tile; the others in phase g or
+//   later) = interval 2 g - 2 for group 0: one full barrier later (the "one barrier more" a staggered pair needs).  The
+//   prologue issues g = 0..4 and waits vmcnt(4) + barrier (g = 0, 1, 2 landed) before B0 of tile 0 is read.
+//   WAR: g overwrites the slot of g - 8, last read in phase <= g - 8 = (g - 5) - 3: three phases before the issue.
+//   Tail: when fewer than two younger half-tiles exist the wait is vmcnt(2) / vmcnt(0).
+// Every wave executes 8 KT + 2 barriers; there is no spin, flag or data-dependent loop.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct Prm {
+  const __bf16* A;      // plain: [M][K]; conv: NHWC [B][H][W][Cin]
+  const __bf16* W;      // plain: [N][K]; conv: [9][N][Cin]
+  __bf16* C;            // [M][N]
+  const unsigned char* zero;   // 64 KiB of zeros (conv: out-of-image taps)
+  int M, N, K;          // K = 9 * Cin in conv mode
+  int H, Wd, Cin;
+};
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
+
+constexpr int HT_BYTES = 16384;   // one half-tile: 128 rows x 128 bytes
+
+template <bool CONV, bool STAG>
+__global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+  // XCD-aware, bijective remap: the workgroups of one XCD get consecutive tiles
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int ntn = p.N >> 8;
+  const int tm = wg / ntn, tn = wg - tm * ntn;
+  const int m0 = tm << 8, n0 = tn << 8;
+  const int KT = p.K >> 6, G = 4 * KT;
+  const unsigned lds0 = (unsigned)(size_t)smem;
+
+  // ---- per-thread DMA sources.  Slot s = j*512 + tid of a half-tile: LDS row i = s >> 3, 16-byte position s & 7 holds the
+  // row's chunk (s & 7) ^ key(i), key(i) = (i >> 1) & 7 (rows of 128 bytes: two rows per 256-byte bank row)
+  const unsigned char* srcA[2][2];
+  const unsigned char* srcB[2][2];
+  int ay[2][2], ax[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int s = j * 512 + tid, i = s >> 3, chunk = (s & 7) ^ ((i >> 1) & 7);
+      const int row = m0 + (i >> 6) * 128 + h * 64 + (i & 63);
+      const int col = n0 + (i >> 5) * 64 + h * 32 + (i & 31);
+      if (CONV) {
+        const int hw = p.H * p.Wd, b = row / hw, rem = row - b * hw;
+        ay[h][j] = rem / p.Wd; ax[h][j] = rem - ay[h][j] * p.Wd;
+        srcA[h][j] = reinterpret_cast<const unsigned char*>(p.A) + ((size_t)row * p.Cin + chunk * 8) * 2;
+        srcB[h][j] = reinterpret_cast<const unsigned char*>(p.W) + ((size_t)col * p.Cin + chunk * 8) * 2;
+      } else {
+        ay[h][j] = ax[h][j] = 0;
+        srcA[h][j] = reinterpret_cast<const unsigned char*>(p.A) + ((size_t)row * p.K + chunk * 8) * 2;
+        srcB[h][j] = reinterpret_cast<const unsigned char*>(p.W) + ((size_t)col * p.K + chunk * 8) * 2;
+      }
+    }
+  const unsigned char* zero = p.zero + (((blockIdx.x & 7) * 512 + tid) << 4);
+
+  // kind 0 = B0, 1 = A0, 2 = B1, 3 = A1 of K tile `t` into ring slot `slot`
+  auto issue = [&](auto kind_c, int t, int slot) {
+    constexpr int KIND = decltype(kind_c)::value, h = KIND >> 1;
+    constexpr bool isA = KIND & 1;
+    size_t koff = (size_t)t * 128;                       // plain: 64 K elements per tile
+    int dy = 0, dx = 0;
+    if (CONV) {
+      const int ck = t / 9, tap = t - ck * 9;
+      dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1;
+      koff = isA ? (size_t)ck * 128 : ((size_t)tap * p.N * p.Cin + ck * 64) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const void* g;
+      if (isA) {
+        if (CONV) {
+          const bool ok = (unsigned)(ay[h][j] + dy) < (unsigned)p.H && (unsigned)(ax[h][j] + dx) < (unsigned)p.Wd;
+          g = ok ? (const void*)(srcA[h][j] + koff + (ptrdiff_t)(dy * p.Wd + dx) * p.Cin * 2) : (const void*)zero;
+        } else g = srcA[h][j] + koff;
+      } else g = srcB[h][j] + koff;
+      __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(lds0 + slot * HT_BYTES + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment reads: lane (lr, lh) reads row lr of a 32-row sub-tile, K chunk (2 ks + lh) ^ key, key = (lr >> 1) & 7
+  const int v = (lh ^ (lr >> 1)) & 7;
+  const unsigned char* fa = smem + (wr * 64 + lr) * 128;
+  const unsigned char* fb = smem + (wc * 32 + lr) * 128;
+  int coff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) coff[ks] = (v ^ (2 * ks)) << 4;
+
+  bf16x8 a[2][4], b[2][4];
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto rdA = [&](int slot) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[mt][ks] = *reinterpret_cast<const bf16x8*>(fa + slot * HT_BYTES + mt * 4096 + coff[ks]);
+  };
+  auto rdB = [&](int slot, bf16x8 (&dst)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) dst[ks] = *reinterpret_cast<const bf16x8*>(fb + slot * HT_BYTES + coff[ks]);
+  };
+
+  auto bar = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // phase Q8 = 4 * (tile parity) + quadrant of the pair of K tiles (2 u, 2 u + 1)
+  auto phase = [&](auto q_c, int u) {
+    constexpr int Q8 = decltype(q_c)::value, PAR = Q8 >> 2, q = Q8 & 3, X = PAR, Y = PAR ^ 1;
+    const int t = 2 * u + PAR, ph = 4 * t + q;
+    // ---------------- read section
+    if constexpr (q == 0) rdA(4 * PAR + 1);
+    if constexpr (q == 1) rdB(4 * PAR + 2, b[Y]);
+    if constexpr (q == 2) rdA(4 * PAR + 3);
+    if constexpr (q == 3) { if (t + 1 < KT) rdB(4 * (PAR ^ 1), b[Y]); }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ph + 5 < G) issue(std::integral_constant<int, (q + 1) & 3>{}, t + (q + 5) / 4, (Q8 + 5) & 7);
+    bar();
+    // ---------------- multiply section
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+    constexpr int MI = (q >= 2) ? 2 : 0, NI = (q == 1 || q == 2) ? 1 : 0, BS = (q == 0 || q == 3) ? X : Y;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        acc[MI + mt][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][ks], b[BS][ks], acc[MI + mt][NI], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (ph + 5 < G) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (ph + 4 < G) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();
+  };
+
+  // ---------------- prologue: half-tiles 0..4 in flight, 0..2 landed, B0 of tile 0 in registers
+  issue(std::integral_constant<int, 0>{}, 0, 0);
+  issue(std::integral_constant<int, 1>{}, 0, 1);
+  issue(std::integral_constant<int, 2>{}, 0, 2);
+  issue(std::integral_constant<int, 3>{}, 0, 3);
+  issue(std::integral_constant<int, 0>{}, 1, 4);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  bar();
+  rdB(0, b[0]);
+  if (STAG && wr == 1) bar();
+  for (int u = 0; u < (KT >> 1); ++u) {
+    phase(std::integral_constant<int, 0>{}, u);
+    phase(std::integral_constant<int, 1>{}, u);
+    phase(std::integral_constant<int, 2>{}, u);
+    phase(std::integral_constant<int, 3>{}, u);
+    phase(std::integral_constant<int, 4>{}, u);
+    phase(std::integral_constant<int, 5>{}, u);
+    phase(std::integral_constant<int, 6>{}, u);
+    phase(std::integral_constant<int, 7>{}, u);
+  }
+  if (STAG && wr == 0) bar();
+
+  // ---------------- epilogue: acc[ah*2+mt][bh][r] = row wr*128 + ah*64 + mt*32 + (r&3) + 8 (r>>2) + 4 lh, column wc*64 + bh*32 + lr
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int col = n0 + wc * 64 + j * 32 + lr;
+        p.C[(size_t)row * p.N + col] = (__bf16)acc[i][j][r];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------- host
+static inline unsigned short f2bf(float f) {
+  unsigned u; memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+static inline float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+struct Shape { const char* name; int conv, B, H, Cin, M, N, K; };
+
+template <bool CONV, bool STAG>
+static int run(const Shape& s) {
+  const int M = s.M, N = s.N, K = s.K;
+  if (M % 256 || N % 256 || K % 128 || (CONV && (s.Cin % 64 || (s.H * s.H) % 1))) { printf("%s: shape not tileable\n", s.name); return 1; }
+  const size_t nA = CONV ? (size_t)M * s.Cin : (size_t)M * K, nW = (size_t)N * K, nC = (size_t)M * N;
+  std::vector<unsigned short> hA(nA), hW(nW);
+  unsigned long long st = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(M * 31 + N * 7 + K);
+  auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 40) & 0xFFFF) / 32768.f - 1.f; };
+  for (auto& x : hA) x = f2bf(rnd());
+  for (auto& x : hW) x = f2bf(rnd());
+  __bf16 *dA, *dW, *dC; unsigned char* dZ;
+  CHECK(hipMalloc(&dA, nA * 2)); CHECK(hipMalloc(&dW, nW * 2)); CHECK(hipMalloc(&dC, nC * 2)); CHECK(hipMalloc(&dZ, 65536));
+  CHECK(hipMemcpy(dA, hA.data(), nA * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(dW, hW.data(), nW * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemset(dZ, 0, 65536));
+  CHECK(hipMemset(dC, 0xFF, nC * 2));
+  Prm p{dA, dW, dC, dZ, M, N, K, s.H, s.H, s.Cin};
+  auto kern = gemm256<CONV, STAG>;
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * HT_BYTES));
+  const dim3 grid((M / 256) * (N / 256)), block(512);
+  hipStream_t stream; CHECK(hipStreamCreate(&stream));
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  // first launch -> reference copy; then repeated launches must reproduce it bit for bit (race screen)
+  hipLaunchKernelGGL(kern, grid, block, 8 * HT_BYTES, stream, p);
+  CHECK(hipGetLastError());
+  CHECK(hipStreamSynchronize(stream));
+  std::vector<unsigned short> hC(nC), hC2(nC);
+  CHECK(hipMemcpy(hC.data(), dC, nC * 2, hipMemcpyDeviceToHost));
+  int unequal_runs = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    CHECK(hipMemsetAsync(dC, 0xFF, nC * 2, stream));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, block, 8 * HT_BYTES, stream, p);
+    CHECK(hipStreamSynchronize(stream));
+    CHECK(hipMemcpy(hC2.data(), dC, nC * 2, hipMemcpyDeviceToHost));
+    if (memcmp(hC.data(), hC2.data(), nC * 2)) ++unequal_runs;
+  }
+  const int NREP = 20;
+  CHECK(hipEventRecord(e0, stream));
+  for (int i = 0; i < NREP; ++i) hipLaunchKernelGGL(kern, grid, block, 8 * HT_BYTES, stream, p);
+  CHECK(hipEventRecord(e1, stream));
+  CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / NREP, tf = 2.0 * M * N * (double)K / (us * 1e-6) / 1e12;
+  // CPU reference on sampled rows (all columns): first / last rows of tiles, wave and sub-tile boundaries, and a stride
+  std::vector<int> rows;
+  for (int r : {0, 1, 31, 32, 63, 64, 127, 128, 191, 192, 255, 256, 257, 511}) if (r < M) rows.push_back(r);
+  for (int r = M - 300; r < M; r += 37) rows.push_back(r);
+  for (int i = 1; i < 40; ++i) rows.push_back((int)(((long long)i * 2654435761ll) % M));
+  double max_err = 0, max_ref = 0; long long bad = 0;
+  std::vector<double> ref(N);
+  for (int row : rows) {
+    for (int n = 0; n < N; ++n) ref[n] = 0;
+    if (!CONV) {
+      for (int n = 0; n < N; ++n) {
+        double acc = 0;
+        const unsigned short *ar = &hA[(size_t)row * K], *wr_ = &hW[(size_t)n * K];
+        for (int k = 0; k < K; ++k) acc += (double)bf2f(ar[k]) * bf2f(wr_[k]);
+        ref[n] = acc;
+      }
+    } else {
+      const int hw = s.H * s.H, bi = row / hw, rem = row % hw, y = rem / s.H, x = rem % s.H;
+      for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if (yy < 0 || yy >= s.H || xx < 0 || xx >= s.H) continue;
+        const unsigned short* ar = &hA[((size_t)(bi * s.H + yy) * s.H + xx) * s.Cin];
+        for (int n = 0; n < N; ++n) {
+          const unsigned short* wv = &hW[((size_t)tap * N + n) * s.Cin];
+          double acc = 0;
+          for (int c = 0; c < s.Cin; ++c) acc += (double)bf2f(ar[c]) * bf2f(wv[c]);
+          ref[n] += acc;
+        }
+      }
+    }
+    for (int n = 0; n < N; ++n) {
+      const double got = bf2f(hC[(size_t)row * N + n]), e = fabs(got - ref[n]);
+      if (e > max_err) max_err = e;
+      if (fabs(ref[n]) > max_ref) max_ref = fabs(ref[n]);
+      if (!(e <= 0.008 * fabs(ref[n]) + 0.02)) ++bad;
+    }
+  }
+  printf("%-44s %s %s  %8.1f us  %7.1f TF/s  | %zu rows checked: max err %.4f (max |ref| %.1f), out of tolerance %lld, "
+         "launch sets differing from the first %d of 4\n", s.name, CONV ? "conv " : "plain", STAG ? "staggered" : "lockstep ", us, tf,
+         rows.size(), max_err, max_ref, bad, unequal_runs);
+  fflush(stdout);
+  CHECK(hipFree(dA)); CHECK(hipFree(dW)); CHECK(hipFree(dC)); CHECK(hipFree(dZ));
+  CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1)); CHECK(hipStreamDestroy(stream));
+  return (bad || unequal_runs) ? 1 : 0;
+}
+
+int main(int argc, char** argv) {
+  const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+  // the 3x3 convs with Cout >= 256 of the headline (B=16, 256x256) and configs[4] (B=8, 512x512) forwards, and their plain twins
+  std::vector<Shape> shapes = {
+      {"B=16 64x64   256->256 (M 65536 K 2304 N 256)", 1, 16, 64, 256, 16 * 64 * 64, 256, 2304},
+      {"B=16 32x32   512->512 (M 16384 K 4608 N 512)", 1, 16, 32, 512, 16 * 32 * 32, 512, 4608},
+      {"B=8 128x128  256->256 (M 131072 K 2304 N 256)", 1, 8, 128, 256, 8 * 128 * 128, 256, 2304},
+      {"B=8  64x64   512->512 (M 32768 K 4608 N 512)", 1, 8, 64, 512, 8 * 64 * 64, 512, 4608},
+  };
+  if (quick) shapes.resize(1);
+  int fails = 0;
+  for (const auto& s : shapes) {
+    fails += run<false, true>(s);
+    fails += run<false, false>(s);
+    fails += run<true, true>(s);
+    if (!quick) fails += run<true, false>(s);
+  }
+  printf(fails ? "FAILED: %d configurations\n" : "all configurations correct and reproducible\n", fails);
+  return fails ? 1 : 0;
+}
