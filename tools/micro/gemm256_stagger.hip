@@ -49,8 +49,9 @@ struct Prm {
   const __bf16* A;      // plain: [M][K]; conv: NHWC [B][H][W][Cin]
   const __bf16* W;      // plain: [N][K]; conv: [9][N][Cin]
   __bf16* C;            // [M][N]
+  float* Cws;           // split-K (gridDim.y > 1): fp32 partials [split][M][N] instead of C
   const unsigned char* zero;   // 64 KiB of zeros (conv: out-of-image taps)
-  int M, N, K;          // K = 9 * Cin in conv mode
+  int M, N, K;          // K = 9 * Cin in conv mode (elements: bf16, or e4m3 bytes with F8)
   int H, Wd, Cin;
 };
 
@@ -58,7 +59,18 @@ struct Prm {
 
 constexpr int HT_BYTES = 16384;   // one half-tile: 128 rows x 128 bytes
 
-template <bool CONV, bool STAG>
+// F8: operands are OCP e4m3 bytes.  Same LDS geometry (rows of 128 bytes = 128 K elements per tile); a lane's 32-byte
+// fragment of v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales) is the chunk pair 4 ks + 2 lh, + 1: twice the K per MFMA cycle.
+// D = how many half-tiles ahead of the phase that issues it a half-tile lies in the stream (5 or 7).  Every half-tile g is read
+// in phase g - 1 exactly, so its slot is free from phase g on; g + 8 reuses it and is issued in phase g + 8 - D.  D = 7 issues it
+// two phases after the slot's last read (group 1 read it in interval 2 g - 1 and waited for those reads at the start of interval
+// 2 g; group 0 issues in interval 2 g + 2): the deepest legal ring -- D = 8 would issue in the interval in which group 1 is still
+// waiting for its reads.  The wait at the end of phase ph must retire every half-tile <= ph + 3 (see RAW above), so D - 3
+// half-tiles stay in flight across it: vmcnt(2 (D - 3)).
+// DBG (timing only, results meaningless): 1 no stores, 2 no DMA inside the loop, 4 no fragment reads inside the loop, 8 no MFMAs.
+// EPI: the bf16 tile goes through a wave-private 16 KiB LDS tile and leaves in 16-byte row-contiguous stores (the direct form
+// stores 2 bytes per lane: 9 us of a 46 us e4m3 launch).
+template <bool CONV, bool STAG, bool F8, int D, int DBG, bool EPI>
 __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,7 +83,10 @@ __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
   const int ntn = p.N >> 8;
   const int tm = wg / ntn, tn = wg - tm * ntn;
   const int m0 = tm << 8, n0 = tn << 8;
-  const int KT = p.K >> 6, G = 4 * KT;
+  constexpr int EB = F8 ? 1 : 2;                         // bytes per K element; a K tile is 128 bytes of every row
+  const int KTall = (p.K * EB) >> 7;
+  const int t0 = (int)((long long)KTall * blockIdx.y / gridDim.y);
+  const int KT = (int)((long long)KTall * (blockIdx.y + 1) / gridDim.y) - t0, G = 4 * KT;   // this split's K tiles (host: even)
   const unsigned lds0 = (unsigned)(size_t)smem;
 
   // ---- per-thread DMA sources.  Slot s = j*512 + tid of a half-tile: LDS row i = s >> 3, 16-byte position s & 7 holds the
@@ -86,29 +101,28 @@ __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
       const int s = j * 512 + tid, i = s >> 3, chunk = (s & 7) ^ ((i >> 1) & 7);
       const int row = m0 + (i >> 6) * 128 + h * 64 + (i & 63);
       const int col = n0 + (i >> 5) * 64 + h * 32 + (i & 31);
+      const size_t rowb = (size_t)(CONV ? p.Cin : p.K) * EB;          // bytes per operand row
+      ay[h][j] = ax[h][j] = 0;
       if (CONV) {
         const int hw = p.H * p.Wd, b = row / hw, rem = row - b * hw;
         ay[h][j] = rem / p.Wd; ax[h][j] = rem - ay[h][j] * p.Wd;
-        srcA[h][j] = reinterpret_cast<const unsigned char*>(p.A) + ((size_t)row * p.Cin + chunk * 8) * 2;
-        srcB[h][j] = reinterpret_cast<const unsigned char*>(p.W) + ((size_t)col * p.Cin + chunk * 8) * 2;
-      } else {
-        ay[h][j] = ax[h][j] = 0;
-        srcA[h][j] = reinterpret_cast<const unsigned char*>(p.A) + ((size_t)row * p.K + chunk * 8) * 2;
-        srcB[h][j] = reinterpret_cast<const unsigned char*>(p.W) + ((size_t)col * p.K + chunk * 8) * 2;
       }
+      srcA[h][j] = reinterpret_cast<const unsigned char*>(p.A) + (size_t)row * rowb + chunk * 16;
+      srcB[h][j] = reinterpret_cast<const unsigned char*>(p.W) + (size_t)col * rowb + chunk * 16;
     }
   const unsigned char* zero = p.zero + (((blockIdx.x & 7) * 512 + tid) << 4);
 
   // kind 0 = B0, 1 = A0, 2 = B1, 3 = A1 of K tile `t` into ring slot `slot`
-  auto issue = [&](auto kind_c, int t, int slot) {
+  auto issue = [&](auto kind_c, int tl, int slot) {
     constexpr int KIND = decltype(kind_c)::value, h = KIND >> 1;
     constexpr bool isA = KIND & 1;
-    size_t koff = (size_t)t * 128;                       // plain: 64 K elements per tile
+    const int t = t0 + tl;                               // K tile of the whole contraction
+    size_t koff = (size_t)t * 128;                       // plain: 128 bytes of every row per tile
     int dy = 0, dx = 0;
     if (CONV) {
       const int ck = t / 9, tap = t - ck * 9;
       dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1;
-      koff = isA ? (size_t)ck * 128 : ((size_t)tap * p.N * p.Cin + ck * 64) * 2;
+      koff = isA ? (size_t)ck * 128 : (size_t)tap * p.N * p.Cin * EB + (size_t)ck * 128;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
       if (isA) {
         if (CONV) {
           const bool ok = (unsigned)(ay[h][j] + dy) < (unsigned)p.H && (unsigned)(ax[h][j] + dx) < (unsigned)p.Wd;
-          g = ok ? (const void*)(srcA[h][j] + koff + (ptrdiff_t)(dy * p.Wd + dx) * p.Cin * 2) : (const void*)zero;
+          g = ok ? (const void*)(srcA[h][j] + koff + (ptrdiff_t)(dy * p.Wd + dx) * p.Cin * EB) : (const void*)zero;
         } else g = srcA[h][j] + koff;
       } else g = srcB[h][j] + koff;
       __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(lds0 + slot * HT_BYTES + (j * 512 + wave * 64) * 16), 16, 0, 0);
@@ -129,9 +143,19 @@ __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
   const unsigned char* fb = smem + (wc * 32 + lr) * 128;
   int coff[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) coff[ks] = (v ^ (2 * ks)) << 4;
+  for (int ks = 0; ks < 4; ++ks)
+    coff[ks] = F8 ? ((4 * (ks >> 1) + 2 * lh + (ks & 1)) ^ ((lr >> 1) & 7)) << 4     // a[..][2 k8], a[..][2 k8 + 1] = one 32-byte fragment
+                  : (v ^ (2 * ks)) << 4;
 
   bf16x8 a[2][4], b[2][4];
+  if (DBG & 4) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[i][k][e] = (__bf16)0.f; b[i][k][e] = (__bf16)0.f; }
+  }
   f32x16 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -163,24 +187,44 @@ __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
     constexpr int Q8 = decltype(q_c)::value, PAR = Q8 >> 2, q = Q8 & 3, X = PAR, Y = PAR ^ 1;
     const int t = 2 * u + PAR, ph = 4 * t + q;
     // ---------------- read section
-    if constexpr (q == 0) rdA(4 * PAR + 1);
-    if constexpr (q == 1) rdB(4 * PAR + 2, b[Y]);
-    if constexpr (q == 2) rdA(4 * PAR + 3);
-    if constexpr (q == 3) { if (t + 1 < KT) rdB(4 * (PAR ^ 1), b[Y]); }
+    if constexpr (!(DBG & 4)) {
+      if constexpr (q == 0) rdA(4 * PAR + 1);
+      if constexpr (q == 1) rdB(4 * PAR + 2, b[Y]);
+      if constexpr (q == 2) rdA(4 * PAR + 3);
+      if constexpr (q == 3) { if (t + 1 < KT) rdB(4 * (PAR ^ 1), b[Y]); }
+    }
     __builtin_amdgcn_sched_barrier(0);
-    if (ph + 5 < G) issue(std::integral_constant<int, (q + 1) & 3>{}, t + (q + 5) / 4, (Q8 + 5) & 7);
+    if (!(DBG & 2) && ph + D < G) issue(std::integral_constant<int, (q + D) & 3>{}, t + (q + D) / 4, (Q8 + D) & 7);
     bar();
     // ---------------- multiply section
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_setprio(1);
     constexpr int MI = (q >= 2) ? 2 : 0, NI = (q == 1 || q == 2) ? 1 : 0, BS = (q == 0 || q == 3) ? X : Y;
+    if constexpr (DBG & 8) {
+    } else if constexpr (F8) {
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      typedef int i32x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+      for (int k8 = 0; k8 < 2; ++k8) {
+        const i32x8 b8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, b[BS][2 * k8]), __builtin_bit_cast(i32x4, b[BS][2 * k8 + 1]), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        acc[MI + mt][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][ks], b[BS][ks], acc[MI + mt][NI], 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) {
+          const i32x8 a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, a[mt][2 * k8]), __builtin_bit_cast(i32x4, a[mt][2 * k8 + 1]), 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[MI + mt][NI] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[MI + mt][NI], 0, 0, 0, 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[MI + mt][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][ks], b[BS][ks], acc[MI + mt][NI], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
-    if (ph + 5 < G) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // in flight after this wait: the half-tiles ph + 4 .. min(ph + D, G - 1)
+    if (D == 7 && ph + 7 < G) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (D == 7 && ph + 6 < G) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (ph + 5 < G) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (ph + 4 < G) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bar();
@@ -192,9 +236,16 @@ __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
   issue(std::integral_constant<int, 2>{}, 0, 2);
   issue(std::integral_constant<int, 3>{}, 0, 3);
   issue(std::integral_constant<int, 0>{}, 1, 4);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (D == 7) {
+    issue(std::integral_constant<int, 1>{}, 1, 5);
+    issue(std::integral_constant<int, 2>{}, 1, 6);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // half-tiles 0, 1, 2 landed; 3 .. 6 in flight
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // half-tiles 0, 1, 2 landed; 3, 4 in flight
+  }
   bar();
   rdB(0, b[0]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slot 0 is refilled (half-tile 8) before group 1's first multiply section
   if (STAG && wr == 1) bar();
   for (int u = 0; u < (KT >> 1); ++u) {
     phase(std::integral_constant<int, 0>{}, u);
@@ -207,6 +258,26 @@ __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
     phase(std::integral_constant<int, 7>{}, u);
   }
   if (STAG && wr == 0) bar();
+  if ((DBG & 1) && acc[0][0][0] != 12345.f) return;      // timing without the epilogue (the accumulators stay live)
+  if (EPI && !p.Cws) {
+    // every DMA has landed and every wave is past its last fragment read (vmcnt(0) + barrier of the last phase, group 0's extra
+    // barrier): wave w takes ring bytes [16 KiB w, +16 KiB) as its [128 rows][64 columns] bf16 tile
+    __bf16* ct = reinterpret_cast<__bf16*>(smem + wave * HT_BYTES);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + j * 32 + lr] = (__bf16)acc[i][j][r];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      const u32x4 vv = *reinterpret_cast<const u32x4*>(ct + row * 64 + ch * 8);
+      *reinterpret_cast<u32x4*>(p.C + (size_t)(m0 + wr * 128 + row) * p.N + n0 + wc * 64 + ch * 8) = vv;
+    }
+    return;
+  }
 
   // ---------------- epilogue: acc[ah*2+mt][bh][r] = row wr*128 + ah*64 + mt*32 + (r&3) + 8 (r>>2) + 4 lh, column wc*64 + bh*32 + lr
 #pragma unroll
@@ -217,7 +288,8 @@ __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int col = n0 + wc * 64 + j * 32 + lr;
-        p.C[(size_t)row * p.N + col] = (__bf16)acc[i][j][r];
+        if (p.Cws) p.Cws[((size_t)blockIdx.y * p.M + row) * p.N + col] = acc[i][j][r];
+        else p.C[(size_t)row * p.N + col] = (__bf16)acc[i][j][r];
       }
 }
 
@@ -228,44 +300,68 @@ static inline unsigned short f2bf(float f) {
   return (unsigned short)(u >> 16);
 }
 static inline float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline float e4m3f(unsigned char b) {   // OCP e4m3fn
+  const int e = (b >> 3) & 15, m = b & 7;
+  const float v = e ? ldexpf(1.f + m / 8.f, e - 7) : ldexpf(m / 8.f, -6);
+  return (b & 0x80) ? -v : v;
+}
 
-struct Shape { const char* name; int conv, B, H, Cin, M, N, K; };
+struct Shape { const char* name; int B, H, Cin, M, N, K; };
 
-template <bool CONV, bool STAG>
-static int run(const Shape& s) {
-  const int M = s.M, N = s.N, K = s.K;
-  if (M % 256 || N % 256 || K % 128 || (CONV && (s.Cin % 64 || (s.H * s.H) % 1))) { printf("%s: shape not tileable\n", s.name); return 1; }
+template <bool CONV, bool STAG, bool F8, int D = 5, int DBG = 0, bool EPI = false>
+static int run(const Shape& s, int nsplit = 1) {
+  const int dbg = DBG;
+  const int M = s.M, N = s.N, K = s.K, EB = F8 ? 1 : 2;
+  const int KT = K * EB / 128;
+  if (M % 256 || N % 256 || (K * EB) % 128 || KT % nsplit || (KT / nsplit) % 2 || KT / nsplit < 2 || (CONV && (s.Cin * EB) % 128)) {
+    printf("%s: shape not tileable (K tiles %d, splits %d)\n", s.name, KT, nsplit); return 1;
+  }
   const size_t nA = CONV ? (size_t)M * s.Cin : (size_t)M * K, nW = (size_t)N * K, nC = (size_t)M * N;
-  std::vector<unsigned short> hA(nA), hW(nW);
+  std::vector<float> fA(nA), fW(nW);                     // the operand VALUES (exactly representable), for the reference
+  std::vector<unsigned char> hA(nA * EB), hW(nW * EB);
   unsigned long long st = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(M * 31 + N * 7 + K);
-  auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 40) & 0xFFFF) / 32768.f - 1.f; };
-  for (auto& x : hA) x = f2bf(rnd());
-  for (auto& x : hW) x = f2bf(rnd());
-  __bf16 *dA, *dW, *dC; unsigned char* dZ;
-  CHECK(hipMalloc(&dA, nA * 2)); CHECK(hipMalloc(&dW, nW * 2)); CHECK(hipMalloc(&dC, nC * 2)); CHECK(hipMalloc(&dZ, 65536));
-  CHECK(hipMemcpy(dA, hA.data(), nA * 2, hipMemcpyHostToDevice));
-  CHECK(hipMemcpy(dW, hW.data(), nW * 2, hipMemcpyHostToDevice));
+  auto rnd16 = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)((st >> 40) & 0xFFFF); };
+  auto fill = [&](std::vector<float>& f, std::vector<unsigned char>& h) {
+    for (size_t i = 0; i < f.size(); ++i) {
+      if (F8) {   // random e4m3 with exponent field <= 8 (|x| < 4): no NaN / overflow codes
+        const unsigned r = rnd16();
+        const unsigned char b = (unsigned char)(((r & 1) << 7) | ((((r >> 1) % 9) & 15) << 3) | ((r >> 8) & 7));
+        h[i] = b; f[i] = e4m3f(b);
+      } else {
+        const unsigned short b = f2bf((float)rnd16() / 32768.f - 1.f);
+        memcpy(&h[2 * i], &b, 2); f[i] = bf2f(b);
+      }
+    }
+  };
+  fill(fA, hA); fill(fW, hW);
+  __bf16 *dA, *dW, *dC; unsigned char* dZ; float* dWs = nullptr;
+  CHECK(hipMalloc(&dA, hA.size())); CHECK(hipMalloc(&dW, hW.size())); CHECK(hipMalloc(&dC, nC * 2)); CHECK(hipMalloc(&dZ, 65536));
+  if (nsplit > 1) CHECK(hipMalloc(&dWs, nC * 4 * nsplit));
+  CHECK(hipMemcpy(dA, hA.data(), hA.size(), hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(dW, hW.data(), hW.size(), hipMemcpyHostToDevice));
   CHECK(hipMemset(dZ, 0, 65536));
-  CHECK(hipMemset(dC, 0xFF, nC * 2));
-  Prm p{dA, dW, dC, dZ, M, N, K, s.H, s.H, s.Cin};
-  auto kern = gemm256<CONV, STAG>;
+  void* dOut = nsplit > 1 ? (void*)dWs : (void*)dC;
+  const size_t outBytes = nsplit > 1 ? nC * 4 * nsplit : nC * 2;
+  CHECK(hipMemset(dOut, 0xFF, outBytes));
+  Prm p{dA, dW, dC, dWs, dZ, M, N, K, s.H, s.H, s.Cin};
+  auto kern = gemm256<CONV, STAG, F8, D, DBG, EPI>;
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * HT_BYTES));
-  const dim3 grid((M / 256) * (N / 256)), block(512);
+  const dim3 grid((M / 256) * (N / 256), nsplit), block(512);
   hipStream_t stream; CHECK(hipStreamCreate(&stream));
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   // first launch -> reference copy; then repeated launches must reproduce it bit for bit (race screen)
   hipLaunchKernelGGL(kern, grid, block, 8 * HT_BYTES, stream, p);
   CHECK(hipGetLastError());
   CHECK(hipStreamSynchronize(stream));
-  std::vector<unsigned short> hC(nC), hC2(nC);
-  CHECK(hipMemcpy(hC.data(), dC, nC * 2, hipMemcpyDeviceToHost));
+  std::vector<unsigned char> hC(outBytes), hC2(outBytes);
+  CHECK(hipMemcpy(hC.data(), dOut, outBytes, hipMemcpyDeviceToHost));
   int unequal_runs = 0;
-  for (int rep = 0; rep < 4; ++rep) {
-    CHECK(hipMemsetAsync(dC, 0xFF, nC * 2, stream));
+  for (int rep = 0; rep < 3; ++rep) {
+    CHECK(hipMemsetAsync(dOut, 0xFF, outBytes, stream));
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, block, 8 * HT_BYTES, stream, p);
     CHECK(hipStreamSynchronize(stream));
-    CHECK(hipMemcpy(hC2.data(), dC, nC * 2, hipMemcpyDeviceToHost));
-    if (memcmp(hC.data(), hC2.data(), nC * 2)) ++unequal_runs;
+    CHECK(hipMemcpy(hC2.data(), dOut, outBytes, hipMemcpyDeviceToHost));
+    if (memcmp(hC.data(), hC2.data(), outBytes)) ++unequal_runs;
   }
   const int NREP = 20;
   CHECK(hipEventRecord(e0, stream));
@@ -274,6 +370,12 @@ static int run(const Shape& s) {
   CHECK(hipEventSynchronize(e1));
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / NREP, tf = 2.0 * M * N * (double)K / (us * 1e-6) / 1e12;
+  auto got_at = [&](int row, int n) -> double {
+    if (nsplit == 1) { unsigned short h; memcpy(&h, &hC[((size_t)row * N + n) * 2], 2); return bf2f(h); }
+    double sum = 0;
+    for (int sp = 0; sp < nsplit; ++sp) { float f; memcpy(&f, &hC[(((size_t)sp * M + row) * N + n) * 4], 4); sum += f; }
+    return sum;
+  };
   // CPU reference on sampled rows (all columns): first / last rows of tiles, wave and sub-tile boundaries, and a stride
   std::vector<int> rows;
   for (int r : {0, 1, 31, 32, 63, 64, 127, 128, 191, 192, 255, 256, 257, 511}) if (r < M) rows.push_back(r);
@@ -281,13 +383,14 @@ static int run(const Shape& s) {
   for (int i = 1; i < 40; ++i) rows.push_back((int)(((long long)i * 2654435761ll) % M));
   double max_err = 0, max_ref = 0; long long bad = 0;
   std::vector<double> ref(N);
+  if (dbg) rows.clear();
   for (int row : rows) {
     for (int n = 0; n < N; ++n) ref[n] = 0;
     if (!CONV) {
       for (int n = 0; n < N; ++n) {
         double acc = 0;
-        const unsigned short *ar = &hA[(size_t)row * K], *wr_ = &hW[(size_t)n * K];
-        for (int k = 0; k < K; ++k) acc += (double)bf2f(ar[k]) * bf2f(wr_[k]);
+        const float *ar = &fA[(size_t)row * K], *wv = &fW[(size_t)n * K];
+        for (int k = 0; k < K; ++k) acc += (double)ar[k] * wv[k];
         ref[n] = acc;
       }
     } else {
@@ -295,48 +398,108 @@ static int run(const Shape& s) {
       for (int tap = 0; tap < 9; ++tap) {
         const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
         if (yy < 0 || yy >= s.H || xx < 0 || xx >= s.H) continue;
-        const unsigned short* ar = &hA[((size_t)(bi * s.H + yy) * s.H + xx) * s.Cin];
+        const float* ar = &fA[((size_t)(bi * s.H + yy) * s.H + xx) * s.Cin];
         for (int n = 0; n < N; ++n) {
-          const unsigned short* wv = &hW[((size_t)tap * N + n) * s.Cin];
+          const float* wv = &fW[((size_t)tap * N + n) * s.Cin];
           double acc = 0;
-          for (int c = 0; c < s.Cin; ++c) acc += (double)bf2f(ar[c]) * bf2f(wv[c]);
+          for (int c = 0; c < s.Cin; ++c) acc += (double)ar[c] * wv[c];
           ref[n] += acc;
         }
       }
     }
     for (int n = 0; n < N; ++n) {
-      const double got = bf2f(hC[(size_t)row * N + n]), e = fabs(got - ref[n]);
+      const double got = got_at(row, n), e = fabs(got - ref[n]);
       if (e > max_err) max_err = e;
       if (fabs(ref[n]) > max_ref) max_ref = fabs(ref[n]);
       if (!(e <= 0.008 * fabs(ref[n]) + 0.02)) ++bad;
     }
   }
-  printf("%-44s %s %s  %8.1f us  %7.1f TF/s  | %zu rows checked: max err %.4f (max |ref| %.1f), out of tolerance %lld, "
-         "launch sets differing from the first %d of 4\n", s.name, CONV ? "conv " : "plain", STAG ? "staggered" : "lockstep ", us, tf,
+  char tag[64];
+  snprintf(tag, sizeof tag, "%s%s%s%s%s", EPI ? " lds-epilogue" : "", (DBG & 1) ? " no-stores" : "", (DBG & 2) ? " no-dma" : "", (DBG & 4) ? " no-ldsreads" : "",
+           (DBG & 8) ? " no-mfma" : "");
+  printf("%-46s %s %s %s D%d split %d%s %7.1f us %7.1f TF/s | %zu rows: max err %.4f (max |ref| %.1f), bad %lld, differing reruns %d/3\n",
+         s.name, CONV ? "conv " : "plain", F8 ? "e4m3" : "bf16", STAG ? "staggered" : "lockstep ", D, nsplit, tag, us, tf,
          rows.size(), max_err, max_ref, bad, unequal_runs);
   fflush(stdout);
   CHECK(hipFree(dA)); CHECK(hipFree(dW)); CHECK(hipFree(dC)); CHECK(hipFree(dZ));
+  if (dWs) CHECK(hipFree(dWs));
   CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1)); CHECK(hipStreamDestroy(stream));
-  return (bad || unequal_runs) ? 1 : 0;
+  return (bad || (unequal_runs && !dbg)) ? 1 : 0;
 }
 
 int main(int argc, char** argv) {
-  const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+  const char* set = argc > 1 ? argv[1] : "bf16";
   // the 3x3 convs with Cout >= 256 of the headline (B=16, 256x256) and configs[4] (B=8, 512x512) forwards, and their plain twins
-  std::vector<Shape> shapes = {
-      {"B=16 64x64   256->256 (M 65536 K 2304 N 256)", 1, 16, 64, 256, 16 * 64 * 64, 256, 2304},
-      {"B=16 32x32   512->512 (M 16384 K 4608 N 512)", 1, 16, 32, 512, 16 * 32 * 32, 512, 4608},
-      {"B=8 128x128  256->256 (M 131072 K 2304 N 256)", 1, 8, 128, 256, 8 * 128 * 128, 256, 2304},
-      {"B=8  64x64   512->512 (M 32768 K 4608 N 512)", 1, 8, 64, 512, 8 * 64 * 64, 512, 4608},
-  };
-  if (quick) shapes.resize(1);
+  const Shape c256{"B=16 64x64   256->256 (M 65536 K 2304 N 256)", 16, 64, 256, 16 * 64 * 64, 256, 2304};
+  const Shape c512{"B=16 32x32   512->512 (M 16384 K 4608 N 512)", 16, 32, 512, 16 * 32 * 32, 512, 4608};
+  const Shape d256{"B=8 128x128  256->256 (M 131072 K 2304 N 256)", 8, 128, 256, 8 * 128 * 128, 256, 2304};
+  const Shape d512{"B=8  64x64   512->512 (M 32768 K 4608 N 512)", 8, 64, 512, 8 * 64 * 64, 512, 4608};
+  const Shape e512{"B=16 16x16   512->512 (M 4096 K 4608 N 512)", 16, 16, 512, 16 * 16 * 16, 512, 4608};
   int fails = 0;
-  for (const auto& s : shapes) {
-    fails += run<false, true>(s);
-    fails += run<false, false>(s);
-    fails += run<true, true>(s);
-    if (!quick) fails += run<true, false>(s);
-  }
+  if (!strcmp(set, "bf16")) {          // first data set (profiles/r03_gemm256_stagger_first_run.txt)
+    for (const Shape* s : {&c256, &c512, &d256, &d512}) {
+      fails += run<false, true, false>(*s);
+      fails += run<false, false, false>(*s);
+      fails += run<true, true, false>(*s);
+      fails += run<true, false, false>(*s);
+    }
+  } else if (!strcmp(set, "fp8")) {    // e4m3 operands, and split-K where a shape has fewer than 256 tiles
+    for (const Shape* s : {&c256, &c512, &d256, &d512}) fails += run<true, true, true>(*s);
+    fails += run<false, true, true>(d512);
+    fails += run<true, false, true>(d512);
+    fails += run<true, true, false>(c512, 2);
+    fails += run<true, true, true>(c512, 2);
+    fails += run<true, true, false>(e512, 4);
+    fails += run<true, true, false>(e512, 6);
+    fails += run<true, true, true>(e512, 6);
+  } else if (!strcmp(set, "depth")) {  // ring depth 5 vs 7 (half-tiles in flight across the waits: 2 vs 4), and the epilogue's share
+    for (const Shape* s : {&c256, &d256, &d512}) {
+      fails += run<true, true, false, 5>(*s);
+      fails += run<true, true, false, 7>(*s);
+      fails += run<true, true, true, 5>(*s);
+      fails += run<true, true, true, 7>(*s);
+    }
+    fails += run<false, true, false, 7>(c256);
+    fails += run<false, true, true, 7>(d512);
+    fails += run<true, false, false, 7>(c256);
+    fails += run<true, true, false, 7, 1>(c256);
+    fails += run<true, true, true, 7, 1>(c256);
+    fails += run<true, true, false, 7>(c512, 2);
+    fails += run<true, true, true, 7>(e512, 6);
+  } else if (!strcmp(set, "dissect")) {   // the LDS epilogue (checked), and where a launch's time goes (timing-only switches)
+    fails += run<true, true, false, 5, 0, true>(c256);
+    fails += run<true, true, true, 5, 0, true>(c256);
+    fails += run<true, true, false, 5, 0, true>(d512);
+    fails += run<true, true, true, 5, 0, true>(d512);
+    fails += run<false, true, false, 5, 0, true>(c256);
+    fails += run<true, true, false, 5, 1>(c256);
+    fails += run<true, true, false, 5, 1 | 2>(c256);
+    fails += run<true, true, false, 5, 1 | 4>(c256);
+    fails += run<true, true, false, 5, 1 | 8>(c256);
+    fails += run<true, true, false, 5, 1 | 2 | 4>(c256);
+    fails += run<true, true, false, 5, 1 | 2 | 8>(c256);
+    fails += run<true, true, false, 5, 1 | 4 | 8>(c256);
+    fails += run<true, true, false, 5, 1 | 2 | 4 | 8>(c256);
+    fails += run<true, false, false, 5, 1 | 2 | 4>(c256);
+    fails += run<true, true, true, 5, 1>(c256);
+    fails += run<true, true, true, 5, 1 | 2>(c256);
+    fails += run<true, true, true, 5, 1 | 4>(c256);
+    fails += run<true, true, true, 5, 1 | 2 | 4>(c256);
+  } else if (!strcmp(set, "dma")) {   // the DMA stream alone: does a deeper ring raise its rate?  (timing only)
+    fails += run<true, true, false, 5, 1>(c256);
+    fails += run<true, true, false, 7, 1>(c256);
+    fails += run<true, true, false, 5, 1 | 8>(c256);
+    fails += run<true, true, false, 7, 1 | 8>(c256);
+    fails += run<true, true, false, 5, 1 | 4 | 8>(c256);
+    fails += run<true, true, false, 7, 1 | 4 | 8>(c256);
+    fails += run<false, true, false, 5, 1 | 4 | 8>(c256);
+    fails += run<false, true, false, 7, 1 | 4 | 8>(c256);
+    fails += run<true, false, false, 7, 1 | 4 | 8>(c256);
+    fails += run<true, true, true, 5, 1 | 4 | 8>(d512);
+    fails += run<true, true, true, 7, 1 | 4 | 8>(d512);
+    fails += run<true, true, true, 5, 1 | 2 | 4>(d512);
+    fails += run<true, true, true, 7, 1>(d512);
+  } else { printf("usage: gemm256_stagger [bf16|fp8|depth|dissect|dma]\n"); return 2; }
   printf(fails ? "FAILED: %d configurations\n" : "all configurations correct and reproducible\n", fails);
   return fails ? 1 : 0;
 }
