@@ -293,6 +293,197 @@ __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
       }
 }
 
+// ------------------------------------------------------------------------------------------------- 256 x 128 tile (Cout = 128)
+// The same eight waves (2 x 4) on a 256 x 128 tile: a wave owns 128 x 32 (four accumulators).  A K tile is THREE half-tiles of
+// 16 KiB -- B (all 128 columns: wave column wc reads rows wc*32 .. +31), A0, A1 -- and TWO phases of 8 MFMAs: (A0, B), (A1, B).
+// Reads: phase p0(t) A0(t); phase p1(t) A1(t) and B(t+1).  With r(g) = the phase that reads half-tile g
+// (B(t): 2t-1, A0(t): 2t, A1(t): 2t+1) the two rules of the staggered pair are (file header, in barrier intervals)
+//   R1  g must be retired by the counted wait at the END of phase r(g) - 2 (group 1 executes that wait in interval 2 r(g) - 2,
+//       group 0 first reads in interval 2 r(g));
+//   R2  g may be issued from phase r(g') + 2 on, g' = the previous occupant of its slot.
+// A ring of 6 slots (two tiles) would force issue and retirement of B(t) into the same phase; with NINE slots (three tiles,
+// 144 KiB) p0(u) issues A0(u+2) and p1(u) issues A1(u+2), B(u+3) -- R2 with equality for all three -- and both waits leave
+// exactly three half-tiles in flight: end of p0(u) keeps A1(u+1), B(u+2), A0(u+2); end of p1(u) keeps A0(u+2), A1(u+2), B(u+3):
+// vmcnt(6).  Once a phase has nothing left to issue the wait is vmcnt(0) (the last three tiles).  The prologue issues
+// g = 0 .. 6 (through B(2)), waits vmcnt(6) (B(0), A0(0), A1(0), B(1) landed) + barrier, and reads B(0).  The body is unrolled
+// over three tiles so every slot index is a constant; B(t+1) is read into a second register set and becomes B at the end of p1.
+template <bool CONV, bool STAG, bool F8>
+__global__ __launch_bounds__(512, 1) void gemm256x128(const Prm p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int ntn = p.N >> 7;
+  const int tm = wg / ntn, tn = wg - tm * ntn;
+  const int m0 = tm << 8, n0 = tn << 7;
+  constexpr int EB = F8 ? 1 : 2;
+  const int KT = (p.K * EB) >> 7;                        // host: a multiple of 3, >= 3
+  const unsigned lds0 = (unsigned)(size_t)smem;
+
+  const unsigned char* srcA[2][2];
+  const unsigned char* srcB[2];
+  int ay[2][2], ax[2][2];
+  const size_t rowb = (size_t)(CONV ? p.Cin : p.K) * EB;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int s = j * 512 + tid, i = s >> 3, chunk = (s & 7) ^ ((i >> 1) & 7);
+    srcB[j] = reinterpret_cast<const unsigned char*>(p.W) + (size_t)(n0 + i) * rowb + chunk * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = m0 + (i >> 6) * 128 + h * 64 + (i & 63);
+      ay[h][j] = ax[h][j] = 0;
+      if (CONV) {
+        const int hw = p.H * p.Wd, b = row / hw, rem = row - b * hw;
+        ay[h][j] = rem / p.Wd; ax[h][j] = rem - ay[h][j] * p.Wd;
+      }
+      srcA[h][j] = reinterpret_cast<const unsigned char*>(p.A) + (size_t)row * rowb + chunk * 16;
+    }
+  }
+  const unsigned char* zero = p.zero + (((blockIdx.x & 7) * 512 + tid) << 4);
+
+  // kind 0 = B, 1 = A0, 2 = A1 of K tile t into ring slot `slot`
+  auto issue = [&](auto kind_c, int t, int slot) {
+    constexpr int KIND = decltype(kind_c)::value, h = KIND == 2 ? 1 : 0;
+    constexpr bool isA = KIND != 0;
+    size_t koff = (size_t)t * 128;
+    int dy = 0, dx = 0;
+    if (CONV) {
+      const int ck = t / 9, tap = t - ck * 9;
+      dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1;
+      koff = isA ? (size_t)ck * 128 : (size_t)tap * p.N * p.Cin * EB + (size_t)ck * 128;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const void* g;
+      if (isA) {
+        if (CONV) {
+          const bool ok = (unsigned)(ay[h][j] + dy) < (unsigned)p.H && (unsigned)(ax[h][j] + dx) < (unsigned)p.Wd;
+          g = ok ? (const void*)(srcA[h][j] + koff + (ptrdiff_t)(dy * p.Wd + dx) * p.Cin * EB) : (const void*)zero;
+        } else g = srcA[h][j] + koff;
+      } else g = srcB[j] + koff;
+      __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(size_t)(lds0 + slot * HT_BYTES + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  const int v = (lh ^ (lr >> 1)) & 7;
+  const unsigned char* fa = smem + (wr * 64 + lr) * 128;
+  const unsigned char* fb = smem + (wc * 32 + lr) * 128;
+  int coff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    coff[ks] = F8 ? ((4 * (ks >> 1) + 2 * lh + (ks & 1)) ^ ((lr >> 1) & 7)) << 4 : (v ^ (2 * ks)) << 4;
+
+  bf16x8 a[2][4], b[4], bn[4];
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  auto rdA = [&](int slot) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[mt][ks] = *reinterpret_cast<const bf16x8*>(fa + slot * HT_BYTES + mt * 4096 + coff[ks]);
+  };
+  auto rdB = [&](int slot, bf16x8 (&dst)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) dst[ks] = *reinterpret_cast<const bf16x8*>(fb + slot * HT_BYTES + coff[ks]);
+  };
+  auto bar = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // phase Q6 = 2 * (tile within the triple) + (0: A0 x B, 1: A1 x B); t = 3 w + Q6 / 2; half-tile g = 3 t + kind sits in slot g mod 9
+  auto phase = [&](auto q_c, int w) {
+    constexpr int Q6 = decltype(q_c)::value, TI = Q6 >> 1, q = Q6 & 1;
+    const int t = 3 * w + TI;
+    if constexpr (q == 0) {
+      rdA((3 * TI + 1) % 9);                                           // A0(t)
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < KT) issue(std::integral_constant<int, 1>{}, t + 2, (3 * (TI + 2) + 1) % 9);
+    } else {
+      rdA((3 * TI + 2) % 9);                                           // A1(t)
+      if (t + 1 < KT) rdB((3 * (TI + 1)) % 9, bn);                      // B(t+1)
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < KT) issue(std::integral_constant<int, 2>{}, t + 2, (3 * (TI + 2) + 2) % 9);
+      if (t + 3 < KT) issue(std::integral_constant<int, 0>{}, t + 3, (3 * (TI + 3)) % 9);
+    }
+    bar();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (F8) {
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      typedef int i32x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int k8 = 0; k8 < 2; ++k8) {
+        const i32x8 b8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, b[2 * k8]), __builtin_bit_cast(i32x4, b[2 * k8 + 1]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const i32x8 a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, a[mt][2 * k8]), __builtin_bit_cast(i32x4, a[mt][2 * k8 + 1]), 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[2 * q + mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[2 * q + mt], 0, 0, 0, 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[2 * q + mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][ks], b[ks], acc[2 * q + mt], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (q == 1) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) b[ks] = bn[ks];
+    }
+    // steady state: three half-tiles stay in flight; once this phase had nothing (or not everything) to issue, drain
+    if (q == 0 ? (t + 2 < KT) : (t + 3 < KT)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();
+  };
+
+  issue(std::integral_constant<int, 0>{}, 0, 0);
+  issue(std::integral_constant<int, 1>{}, 0, 1);
+  issue(std::integral_constant<int, 2>{}, 0, 2);
+  issue(std::integral_constant<int, 0>{}, 1, 3);
+  issue(std::integral_constant<int, 1>{}, 1, 4);
+  issue(std::integral_constant<int, 2>{}, 1, 5);
+  issue(std::integral_constant<int, 0>{}, 2, 6);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // B(0), A0(0), A1(0), B(1) landed
+  bar();
+  rdB(0, b);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) bn[ks] = b[ks];
+  if (STAG && wr == 1) bar();
+  for (int w = 0; w < KT / 3; ++w) {
+    phase(std::integral_constant<int, 0>{}, w);
+    phase(std::integral_constant<int, 1>{}, w);
+    phase(std::integral_constant<int, 2>{}, w);
+    phase(std::integral_constant<int, 3>{}, w);
+    phase(std::integral_constant<int, 4>{}, w);
+    phase(std::integral_constant<int, 5>{}, w);
+  }
+  if (STAG && wr == 0) bar();
+  // wave-private LDS tile [128 rows][32 columns] bf16 (8 KiB of the ring), then 16-byte row-contiguous stores
+  __bf16* ct = reinterpret_cast<__bf16*>(smem + wave * HT_BYTES);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = (__bf16)acc[i][r];
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 16 + (lane >> 2), ch = lane & 3;
+    const u32x4 vv = *reinterpret_cast<const u32x4*>(ct + row * 32 + ch * 8);
+    *reinterpret_cast<u32x4*>(p.C + (size_t)(m0 + wr * 128 + row) * p.N + n0 + wc * 32 + ch * 8) = vv;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------- host
 static inline unsigned short f2bf(float f) {
   unsigned u; memcpy(&u, &f, 4);
@@ -308,12 +499,13 @@ static inline float e4m3f(unsigned char b) {   // OCP e4m3fn
 
 struct Shape { const char* name; int B, H, Cin, M, N, K; };
 
-template <bool CONV, bool STAG, bool F8, int D = 5, int DBG = 0, bool EPI = false>
+template <bool CONV, bool STAG, bool F8, int D = 5, int DBG = 0, bool EPI = false, int BN = 256>
 static int run(const Shape& s, int nsplit = 1) {
   const int dbg = DBG;
   const int M = s.M, N = s.N, K = s.K, EB = F8 ? 1 : 2;
   const int KT = K * EB / 128;
-  if (M % 256 || N % 256 || (K * EB) % 128 || KT % nsplit || (KT / nsplit) % 2 || KT / nsplit < 2 || (CONV && (s.Cin * EB) % 128)) {
+  if (M % 256 || N % BN || (K * EB) % 128 || KT % nsplit || (BN == 256 ? (KT / nsplit) % 2 || KT / nsplit < 2 : KT % 3 || nsplit != 1) ||
+      (CONV && (s.Cin * EB) % 128)) {
     printf("%s: shape not tileable (K tiles %d, splits %d)\n", s.name, KT, nsplit); return 1;
   }
   const size_t nA = CONV ? (size_t)M * s.Cin : (size_t)M * K, nW = (size_t)N * K, nC = (size_t)M * N;
@@ -344,13 +536,15 @@ static int run(const Shape& s, int nsplit = 1) {
   const size_t outBytes = nsplit > 1 ? nC * 4 * nsplit : nC * 2;
   CHECK(hipMemset(dOut, 0xFF, outBytes));
   Prm p{dA, dW, dC, dWs, dZ, M, N, K, s.H, s.H, s.Cin};
-  auto kern = gemm256<CONV, STAG, F8, D, DBG, EPI>;
-  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * HT_BYTES));
-  const dim3 grid((M / 256) * (N / 256), nsplit), block(512);
+  void (*kern)(Prm);
+  if constexpr (BN == 256) kern = gemm256<CONV, STAG, F8, D, DBG, EPI>; else kern = gemm256x128<CONV, STAG, F8>;
+  constexpr int LDS_BYTES = (BN == 256 ? 8 : 9) * HT_BYTES;
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  const dim3 grid((M / 256) * (N / BN), nsplit), block(512);
   hipStream_t stream; CHECK(hipStreamCreate(&stream));
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   // first launch -> reference copy; then repeated launches must reproduce it bit for bit (race screen)
-  hipLaunchKernelGGL(kern, grid, block, 8 * HT_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, grid, block, LDS_BYTES, stream, p);
   CHECK(hipGetLastError());
   CHECK(hipStreamSynchronize(stream));
   std::vector<unsigned char> hC(outBytes), hC2(outBytes);
@@ -358,14 +552,14 @@ static int run(const Shape& s, int nsplit = 1) {
   int unequal_runs = 0;
   for (int rep = 0; rep < 3; ++rep) {
     CHECK(hipMemsetAsync(dOut, 0xFF, outBytes, stream));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, block, 8 * HT_BYTES, stream, p);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, block, LDS_BYTES, stream, p);
     CHECK(hipStreamSynchronize(stream));
     CHECK(hipMemcpy(hC2.data(), dOut, outBytes, hipMemcpyDeviceToHost));
     if (memcmp(hC.data(), hC2.data(), outBytes)) ++unequal_runs;
   }
   const int NREP = 20;
   CHECK(hipEventRecord(e0, stream));
-  for (int i = 0; i < NREP; ++i) hipLaunchKernelGGL(kern, grid, block, 8 * HT_BYTES, stream, p);
+  for (int i = 0; i < NREP; ++i) hipLaunchKernelGGL(kern, grid, block, LDS_BYTES, stream, p);
   CHECK(hipEventRecord(e1, stream));
   CHECK(hipEventSynchronize(e1));
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -415,7 +609,7 @@ static int run(const Shape& s, int nsplit = 1) {
     }
   }
   char tag[64];
-  snprintf(tag, sizeof tag, "%s%s%s%s%s", EPI ? " lds-epilogue" : "", (DBG & 1) ? " no-stores" : "", (DBG & 2) ? " no-dma" : "", (DBG & 4) ? " no-ldsreads" : "",
+  snprintf(tag, sizeof tag, "%s%s%s%s%s%s", BN == 128 ? " TILE-256x128" : "", EPI ? " lds-epilogue" : "", (DBG & 1) ? " no-stores" : "", (DBG & 2) ? " no-dma" : "", (DBG & 4) ? " no-ldsreads" : "",
            (DBG & 8) ? " no-mfma" : "");
   printf("%-46s %s %s %s D%d split %d%s %7.1f us %7.1f TF/s | %zu rows: max err %.4f (max |ref| %.1f), bad %lld, differing reruns %d/3\n",
          s.name, CONV ? "conv " : "plain", F8 ? "e4m3" : "bf16", STAG ? "staggered" : "lockstep ", D, nsplit, tag, us, tf,
@@ -499,7 +693,18 @@ int main(int argc, char** argv) {
     fails += run<true, true, true, 7, 1 | 4 | 8>(d512);
     fails += run<true, true, true, 5, 1 | 2 | 4>(d512);
     fails += run<true, true, true, 7, 1>(d512);
-  } else { printf("usage: gemm256_stagger [bf16|fp8|depth|dissect|dma]\n"); return 2; }
+  } else if (!strcmp(set, "n128")) {   // the 256 x 128 tile on the Cout = 128 convs (gemm16_kernel: 128.6 us / 257.9 us for the first two)
+    const Shape f128{"B=16 128x128 128->128 (M 262144 K 1152 N 128)", 16, 128, 128, 16 * 128 * 128, 128, 1152};
+    const Shape g128{"B=8 256x256  128->128 (M 524288 K 1152 N 128)", 8, 256, 128, 8 * 256 * 256, 128, 1152};
+    const Shape h128{"B=16 128x128 256->128 (M 262144 K 2304 N 128)", 16, 128, 256, 16 * 128 * 128, 128, 2304};
+    fails += run<true, true, false, 5, 0, false, 128>(f128);
+    fails += run<true, false, false, 5, 0, false, 128>(f128);
+    fails += run<true, true, true, 5, 0, false, 128>(f128);
+    fails += run<true, true, false, 5, 0, false, 128>(h128);
+    fails += run<true, true, true, 5, 0, false, 128>(h128);
+    fails += run<true, true, false, 5, 0, false, 128>(c256);
+    if (argc > 2) { fails += run<false, true, false, 5, 0, false, 128>(f128); fails += run<true, true, false, 5, 0, false, 128>(g128); }
+  } else { printf("usage: gemm256_stagger [bf16|fp8|depth|dissect|dma|n128]\n"); return 2; }
   printf(fails ? "FAILED: %d configurations\n" : "all configurations correct and reproducible\n", fails);
   return fails ? 1 : 0;
 }
