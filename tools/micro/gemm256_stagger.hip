@@ -704,7 +704,10 @@ int main(int argc, char** argv) {
     fails += run<true, true, true, 5, 0, false, 128>(h128);
     fails += run<true, true, false, 5, 0, false, 128>(c256);
     if (argc > 2) { fails += run<false, true, false, 5, 0, false, 128>(f128); fails += run<true, true, false, 5, 0, false, 128>(g128); }
-  } else { printf("usage: gemm256_stagger [bf16|fp8|depth|dissect|dma|n128]\n"); return 2; }
+  } else if (!strcmp(set, "n128b")) {  // 128 tiles of 256 x 256 = 256 tiles of 256 x 128: the K split avoided?
+    fails += run<true, true, false, 5, 0, false, 128>(c512);
+    fails += run<true, true, true, 5, 0, false, 128>(c512);
+  } else { printf("usage: gemm256_stagger [bf16|fp8|depth|dissect|dma|n128|n128b]\n"); return 2; }
   printf(fails ? "FAILED: %d configurations\n" : "all configurations correct and reproducible\n", fails);
   return fails ? 1 : 0;
 }
