@@ -484,6 +484,10 @@ __global__ __launch_bounds__(512, 1) void gemm256x128(const Prm p) {
   }
 }
 
+// the strip kernel lives in gemm256_strip.hip (built without -amdgpu-mfma-vgpr-form: its accumulators go to AGPRs), which includes this file
+template <bool STAG, bool F8>
+__global__ void gemm256_strip(const Prm p);
+
 // ------------------------------------------------------------------------------------------------- host
 static inline unsigned short f2bf(float f) {
   unsigned u; memcpy(&u, &f, 4);
@@ -504,7 +508,9 @@ static int run(const Shape& s, int nsplit = 1) {
   const int dbg = DBG;
   const int M = s.M, N = s.N, K = s.K, EB = F8 ? 1 : 2;
   const int KT = K * EB / 128;
-  if (M % 256 || N % BN || (K * EB) % 128 || KT % nsplit || (BN == 256 ? (KT / nsplit) % 2 || KT / nsplit < 2 : KT % 3 || nsplit != 1) ||
+  constexpr int BNW = BN == 257 ? 256 : BN;              // BN = 257: the strip kernel (256 x 256 tile)
+  if (BN == 257 && (!CONV || KT % 6 || nsplit != 1)) { printf("%s: strip kernel needs conv, K tiles %% 6 == 0\n", s.name); return 1; }
+  if (M % 256 || N % BNW || (K * EB) % 128 || KT % nsplit || (BN == 256 ? (KT / nsplit) % 2 || KT / nsplit < 2 : KT % 3 || nsplit != 1) ||
       (CONV && (s.Cin * EB) % 128)) {
     printf("%s: shape not tileable (K tiles %d, splits %d)\n", s.name, KT, nsplit); return 1;
   }
@@ -527,7 +533,10 @@ static int run(const Shape& s, int nsplit = 1) {
   };
   fill(fA, hA); fill(fW, hW);
   __bf16 *dA, *dW, *dC; unsigned char* dZ; float* dWs = nullptr;
-  CHECK(hipMalloc(&dA, hA.size())); CHECK(hipMalloc(&dW, hW.size())); CHECK(hipMalloc(&dC, nC * 2)); CHECK(hipMalloc(&dZ, 65536));
+  // the 64 KiB zero page sits behind A in the same allocation (the strip kernel addresses it as a 32-bit offset from A)
+  const size_t zoff = (hA.size() + 255) & ~(size_t)255;
+  CHECK(hipMalloc(&dA, zoff + 65536)); CHECK(hipMalloc(&dW, hW.size())); CHECK(hipMalloc(&dC, nC * 2));
+  dZ = reinterpret_cast<unsigned char*>(dA) + zoff;
   if (nsplit > 1) CHECK(hipMalloc(&dWs, nC * 4 * nsplit));
   CHECK(hipMemcpy(dA, hA.data(), hA.size(), hipMemcpyHostToDevice));
   CHECK(hipMemcpy(dW, hW.data(), hW.size(), hipMemcpyHostToDevice));
@@ -537,10 +546,12 @@ static int run(const Shape& s, int nsplit = 1) {
   CHECK(hipMemset(dOut, 0xFF, outBytes));
   Prm p{dA, dW, dC, dWs, dZ, M, N, K, s.H, s.H, s.Cin};
   void (*kern)(Prm);
-  if constexpr (BN == 256) kern = gemm256<CONV, STAG, F8, D, DBG, EPI>; else kern = gemm256x128<CONV, STAG, F8>;
-  constexpr int LDS_BYTES = (BN == 256 ? 8 : 9) * HT_BYTES;
+  if constexpr (BN == 256) kern = gemm256<CONV, STAG, F8, D, DBG, EPI>;
+  else if constexpr (BN == 257) kern = gemm256_strip<STAG, F8>;
+  else kern = gemm256x128<CONV, STAG, F8>;
+  constexpr int LDS_BYTES = BN == 256 ? 8 * HT_BYTES : BN == 257 ? 4 * HT_BYTES + 2 * (32768 + 1024) + 1024 : 9 * HT_BYTES;
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  const dim3 grid((M / 256) * (N / BN), nsplit), block(512);
+  const dim3 grid((M / 256) * (N / BNW), nsplit), block(512);
   hipStream_t stream; CHECK(hipStreamCreate(&stream));
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   // first launch -> reference copy; then repeated launches must reproduce it bit for bit (race screen)
@@ -609,18 +620,19 @@ static int run(const Shape& s, int nsplit = 1) {
     }
   }
   char tag[64];
-  snprintf(tag, sizeof tag, "%s%s%s%s%s%s", BN == 128 ? " TILE-256x128" : "", EPI ? " lds-epilogue" : "", (DBG & 1) ? " no-stores" : "", (DBG & 2) ? " no-dma" : "", (DBG & 4) ? " no-ldsreads" : "",
+  snprintf(tag, sizeof tag, "%s%s%s%s%s%s", BN == 128 ? " TILE-256x128" : BN == 257 ? " A-STRIPS" : "", EPI ? " lds-epilogue" : "", (DBG & 1) ? " no-stores" : "", (DBG & 2) ? " no-dma" : "", (DBG & 4) ? " no-ldsreads" : "",
            (DBG & 8) ? " no-mfma" : "");
   printf("%-46s %s %s %s D%d split %d%s %7.1f us %7.1f TF/s | %zu rows: max err %.4f (max |ref| %.1f), bad %lld, differing reruns %d/3\n",
          s.name, CONV ? "conv " : "plain", F8 ? "e4m3" : "bf16", STAG ? "staggered" : "lockstep ", D, nsplit, tag, us, tf,
          rows.size(), max_err, max_ref, bad, unequal_runs);
   fflush(stdout);
-  CHECK(hipFree(dA)); CHECK(hipFree(dW)); CHECK(hipFree(dC)); CHECK(hipFree(dZ));
+  CHECK(hipFree(dA)); CHECK(hipFree(dW)); CHECK(hipFree(dC));
   if (dWs) CHECK(hipFree(dWs));
   CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1)); CHECK(hipStreamDestroy(stream));
   return (bad || (unequal_runs && !dbg)) ? 1 : 0;
 }
 
+#ifndef GEMM256_NO_MAIN
 int main(int argc, char** argv) {
   const char* set = argc > 1 ? argv[1] : "bf16";
   // the 3x3 convs with Cout >= 256 of the headline (B=16, 256x256) and configs[4] (B=8, 512x512) forwards, and their plain twins
@@ -711,3 +723,4 @@ int main(int argc, char** argv) {
   printf(fails ? "FAILED: %d configurations\n" : "all configurations correct and reproducible\n", fails);
   return fails ? 1 : 0;
 }
+#endif
