@@ -10,8 +10,9 @@
 #include "gemm256_stagger.hip"
 
 // ------------------------------------------------------------------------------------------------- 256 x 256 tile, A from row strips
-// WRITTEN AT THE END OF ROUND 3 AND NOT YET RUN ON HARDWARE (the round's GPU minutes were spent): `gemm256_stagger strip` is the
-// first thing to run in round 4.  DESIGN.md 9.2 derives it; in short:
+// Written at the end of round 3 after the CPU checks (strip_index_check.py, schedule_check.py) and run once
+// (profiles/r03_gemm256_strip_first_run.txt): correct and bit-reproducible, 82.2 us against 85.2 us for plain staging (B=16, 64x64,
+// 256 -> 256, bf16).  DESIGN.md 9.2 derives it; in short:
 //  * K order: 128-byte channel chunk ck outer, kernel row dy, then the three taps dx of that row (K tile T = 3 G + dx + 1,
 //    group G = 3 ck + dy + 1).  Per group ONE strip is staged: LDS row rho = pixel m0 + rho of the tile shifted by dy image rows
 //    (rho = 0 .. 255), row 256 = pixel m0 - 1, row 257 = pixel m0 + 256, row 258 = zeros; a pixel whose image row y has y + dy
@@ -264,11 +265,18 @@ __global__ __launch_bounds__(512, 1) void gemm256_strip(const Prm p) {
 }
 
 
-int main() {
+int main(int argc, char** argv) {
   const Shape c256{"B=16 64x64   256->256 (M 65536 K 2304 N 256)", 16, 64, 256, 16 * 64 * 64, 256, 2304};
   const Shape d256{"B=8 128x128  256->256 (M 131072 K 2304 N 256)", 8, 128, 256, 8 * 128 * 128, 256, 2304};
   const Shape d512{"B=8  64x64   512->512 (M 32768 K 4608 N 512)", 8, 64, 512, 8 * 64 * 64, 512, 4608};
   int fails = 0;
+  if (argc > 1 && !strcmp(argv[1], "quick")) {               // one shape, strips against plain staging
+    fails += run<true, true, false, 5, 0, false, 257>(c256);
+    fails += run<true, true, false, 5, 0, true>(c256);
+    fails += run<true, true, true, 5, 0, false, 257>(c256);
+    printf(fails ? "FAILED: %d configurations\n" : "all configurations correct and reproducible\n", fails);
+    return fails ? 1 : 0;
+  }
   for (const Shape* s : {&c256, &d256, &d512}) {
     fails += run<true, true, false, 5, 0, true>(*s);          // plain staging, LDS epilogue (this build's flags)
     fails += run<true, true, false, 5, 0, false, 257>(*s);    // strips
