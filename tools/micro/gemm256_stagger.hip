@@ -53,7 +53,12 @@ struct Prm {
   const unsigned char* zero;   // 64 KiB of zeros (conv: out-of-image taps)
   int M, N, K;          // K = 9 * Cin in conv mode (elements: bf16, or e4m3 bytes with F8)
   int H, Wd, Cin;
+  unsigned long long* clk;   // [0] shader-clock cycles, [1] 100 MHz wall-clock ticks of workgroup 0's run: the effective clock of the launch
 };
+
+// s_memtime / s_memrealtime land in SGPRs: no vector register is held across the kernel
+#define CLK_BEGIN const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
+#define CLK_END(p) if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (p).clk) { (p).clk[0] = __builtin_readcyclecounter() - clk_c0; (p).clk[1] = wall_clock64() - clk_w0; }
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
 
@@ -73,6 +78,7 @@ constexpr int HT_BYTES = 16384;   // one half-tile: 128 rows x 128 bytes
 template <bool CONV, bool STAG, bool F8, int D, int DBG, bool EPI>
 __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  CLK_BEGIN
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int lr = lane & 31, lh = lane >> 5;
@@ -258,6 +264,7 @@ __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
     phase(std::integral_constant<int, 7>{}, u);
   }
   if (STAG && wr == 0) bar();
+  CLK_END(p)
   if ((DBG & 1) && acc[0][0][0] != 12345.f) return;      // timing without the epilogue (the accumulators stay live)
   if (EPI && !p.Cws) {
     // every DMA has landed and every wave is past its last fragment read (vmcnt(0) + barrier of the last phase, group 0's extra
@@ -310,6 +317,7 @@ __global__ __launch_bounds__(512, 1) void gemm256(const Prm p) {
 template <bool CONV, bool STAG, bool F8>
 __global__ __launch_bounds__(512, 1) void gemm256x128(const Prm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  CLK_BEGIN
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int lr = lane & 31, lh = lane >> 5;
@@ -469,6 +477,7 @@ __global__ __launch_bounds__(512, 1) void gemm256x128(const Prm p) {
     phase(std::integral_constant<int, 5>{}, w);
   }
   if (STAG && wr == 0) bar();
+  CLK_END(p)
   // wave-private LDS tile [128 rows][32 columns] bf16 (8 KiB of the ring), then 16-byte row-contiguous stores
   __bf16* ct = reinterpret_cast<__bf16*>(smem + wave * HT_BYTES);
 #pragma unroll
@@ -544,7 +553,8 @@ static int run(const Shape& s, int nsplit = 1) {
   void* dOut = nsplit > 1 ? (void*)dWs : (void*)dC;
   const size_t outBytes = nsplit > 1 ? nC * 4 * nsplit : nC * 2;
   CHECK(hipMemset(dOut, 0xFF, outBytes));
-  Prm p{dA, dW, dC, dWs, dZ, M, N, K, s.H, s.H, s.Cin};
+  unsigned long long* dClk; CHECK(hipMalloc(&dClk, 16)); CHECK(hipMemset(dClk, 0, 16));
+  Prm p{dA, dW, dC, dWs, dZ, M, N, K, s.H, s.H, s.Cin, dClk};
   void (*kern)(Prm);
   if constexpr (BN == 256) kern = gemm256<CONV, STAG, F8, D, DBG, EPI>;
   else if constexpr (BN == 257) kern = gemm256_strip<STAG, F8>;
@@ -575,6 +585,9 @@ static int run(const Shape& s, int nsplit = 1) {
   CHECK(hipEventSynchronize(e1));
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / NREP, tf = 2.0 * M * N * (double)K / (us * 1e-6) / 1e12;
+  unsigned long long hClk[2] = {0, 0};
+  CHECK(hipMemcpy(hClk, dClk, 16, hipMemcpyDeviceToHost));
+  const double ghz = hClk[1] ? (double)hClk[0] / ((double)hClk[1] * 10.0) : 0.0;   // cycles per 10 ns tick -> GHz (workgroup 0, K loop only)
   auto got_at = [&](int row, int n) -> double {
     if (nsplit == 1) { unsigned short h; memcpy(&h, &hC[((size_t)row * N + n) * 2], 2); return bf2f(h); }
     double sum = 0;
@@ -622,11 +635,11 @@ static int run(const Shape& s, int nsplit = 1) {
   char tag[64];
   snprintf(tag, sizeof tag, "%s%s%s%s%s%s", BN == 128 ? " TILE-256x128" : BN == 257 ? " A-STRIPS" : "", EPI ? " lds-epilogue" : "", (DBG & 1) ? " no-stores" : "", (DBG & 2) ? " no-dma" : "", (DBG & 4) ? " no-ldsreads" : "",
            (DBG & 8) ? " no-mfma" : "");
-  printf("%-46s %s %s %s D%d split %d%s %7.1f us %7.1f TF/s | %zu rows: max err %.4f (max |ref| %.1f), bad %lld, differing reruns %d/3\n",
-         s.name, CONV ? "conv " : "plain", F8 ? "e4m3" : "bf16", STAG ? "staggered" : "lockstep ", D, nsplit, tag, us, tf,
+  printf("%-46s %s %s %s D%d split %d%s %7.1f us %7.1f TF/s %.2f GHz | %zu rows: max err %.4f (max |ref| %.1f), bad %lld, differing reruns %d/3\n",
+         s.name, CONV ? "conv " : "plain", F8 ? "e4m3" : "bf16", STAG ? "staggered" : "lockstep ", D, nsplit, tag, us, tf, ghz,
          rows.size(), max_err, max_ref, bad, unequal_runs);
   fflush(stdout);
-  CHECK(hipFree(dA)); CHECK(hipFree(dW)); CHECK(hipFree(dC));
+  CHECK(hipFree(dA)); CHECK(hipFree(dW)); CHECK(hipFree(dC)); CHECK(hipFree(dClk));
   if (dWs) CHECK(hipFree(dWs));
   CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1)); CHECK(hipStreamDestroy(stream));
   return (bad || (unequal_runs && !dbg)) ? 1 : 0;

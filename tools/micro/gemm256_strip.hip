@@ -33,6 +33,7 @@
 template <bool STAG, bool F8>
 __global__ __launch_bounds__(512, 1) void gemm256_strip(const Prm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  CLK_BEGIN
   constexpr int EB = F8 ? 1 : 2;
   constexpr int STRIP_BYTES = 32768 + 1024, STRIP0 = 4 * HT_BYTES, DUMMY = STRIP0 + 2 * STRIP_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_strip(const Prm p) {
     phase(std::integral_constant<int, 21>{}, u); phase(std::integral_constant<int, 22>{}, u); phase(std::integral_constant<int, 23>{}, u);
   }
   if (STAG && wr == 0) bar();
+  CLK_END(p)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail's dummies
   bar();
   __bf16* ct = reinterpret_cast<__bf16*>(smem + wave * HT_BYTES);
