@@ -1,0 +1,70 @@
+"""CPU-side checks of the round-4 groundwork under tools/micro/ (DESIGN.md 9.1-9.2): NOT product code -- these tests only make the
+claims of that section reproducible: the strip kernel's index arithmetic, the DMA / barrier schedules of the eight-wave tiles in
+the barrier-interval model (and that the model flags broken schedules), and that the kernels compile for gfx950 without scratch
+(a scratch reload is a VMEM operation and would corrupt their counted vmcnt waits)."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MICRO = os.path.join(ROOT, "tools", "micro")
+
+
+def test_strip_kernel_index_arithmetic():
+    r = subprocess.run([sys.executable, os.path.join(MICRO, "strip_index_check.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "conflict-free for every start row: True" in r.stdout and "FAILED" not in r.stdout
+
+
+def test_tile_schedules_in_the_barrier_interval_model():
+    sys.path.insert(0, MICRO)
+    try:
+        import schedule_check as S
+    finally:
+        sys.path.pop(0)
+    for sc in [S.gemm256(2, 5), S.gemm256(36, 5), S.gemm256(2, 7), S.gemm256(36, 7), S.gemm256x128(3), S.gemm256x128(36), S.strip(6), S.strip(36)]:
+        assert sc.check() == [], (sc.name, sc.check()[:3])
+    # the model has teeth: a looser wait in the strip schedule, and a six-slot ring for the 256 x 128 tile, are violations
+    s = S.strip(18)
+    for P in s.phases:
+        P["wait"] = 10
+    assert any(e.startswith("RAW") for e in s.check())
+    s = S.gemm256x128(9)
+    fix = lambda l: [(it, (r % 6) if isinstance(r, int) else r) for it, r in l]
+    s.pro_issues = fix(s.pro_issues)
+    for P in s.phases:
+        P["issues"] = fix(P["issues"])
+    assert any(e.startswith("WAR") for e in s.check())
+    # issuing every half-tile one phase later than ring depth 5 allows breaks read-after-write
+    s = S.gemm256(8, 5)
+    for ph in range(len(s.phases) - 1, 0, -1):
+        s.phases[ph]["issues"] = s.phases[ph - 1]["issues"]
+    s.phases[0]["issues"] = []
+    assert any(e.startswith("RAW") for e in s.check())
+
+
+@pytest.mark.parametrize("src,flags", [("gemm256_stagger.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]), ("gemm256_strip.hip", [])])
+def test_groundwork_kernels_compile_without_scratch(src, flags, tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "k.s"
+    r = subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", *flags, "--cuda-device-only", "-S", os.path.join(MICRO, src), "-o", str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    kernels = re.findall(r"^(_Z\d+gemm256\w*):", asm, flags=re.M)
+    scratch = re.findall(r"; ScratchSize: (\d+)", asm)
+    assert len(kernels) >= 3 and len(scratch) >= len(kernels)
+    assert all(int(x) == 0 for x in scratch), scratch
+    if src == "gemm256_strip.hip":
+        body = asm[asm.index("_Z13gemm256_stripILb1ELb0EEv3Prm:"):]
+        body = body[:body.index("s_endpgm")]
+        waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)
+        # 24 phases + prologue with the schedule's constants, one final drain, nothing inserted by the compiler
+        assert sorted(set(waits)) == ["0", "10", "8"] and waits.count("0") == 1 and waits.count("8") == 13 and waits.count("10") == 12, waits
+        assert body.count("s_barrier") == 52 and body.count("v_mfma_f32_32x32x16_bf16") == 192
