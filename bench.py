@@ -12,11 +12,14 @@ work, so  images/sec = N_gpus * B / (T * seconds_per_step); the K timed steps ar
 schedule run through the product C ABI (ddpmir_ddrm_sample_loop with start_step/num_steps).  `--full` runs the whole
 T-step restoration instead (minutes).
 
-The headline keys of the JSON line are those of configs[1].  At N=1 with the default workload the line also carries a
-`workloads` array: short slices of the other BASELINE configurations run in the same process (configs[2] and [3] per-GPU
-shapes, configs[4] shape in bf16 and fp8 mode, configs[0] in full, the three shapes the reference's notebooks left a tqdm
-rate for, and the headline workload with the no-max attention kernel disabled = its worst case), each with its own
-roofline object (`--no-workloads` skips them).
+The LAST stdout line is the one JSON object of the contract and stays below LINE_LIMIT characters (the driver keeps an
+8 000-character tail of stdout + stderr; round 3's 24 KB line was cut in half there).  The headline keys are those of
+configs[1].  At N=1 with the default workload, AFTER the headline has been measured, a fresh child process runs short
+slices of the other BASELINE configurations (configs[2] and [3] per-GPU shapes, configs[4] shape in bf16 and fp8 mode,
+configs[0] in full, the three shapes the reference's notebooks left a tqdm rate for, and the headline workload with the
+no-max attention kernel disabled = its worst case): a device fault in a slice cannot take the headline with it.  Their
+full records (each with its own roofline object) go to gpurun_out/bench_workloads.json; the line carries the compact
+`workloads_summary` (id, ms_per_step, images_per_sec, roofline_frac).  `--no-workloads` skips them.
 
   python bench.py                       # 1 GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -114,7 +117,7 @@ def run_workload(w: dict, env, dev, K: int, W: int, full: bool = False, graph: i
     sampling loop, and read the HIP-event profile classes.  Returns (summary dict, timing/profile details)."""
     import torch
     from ddpm_image_restoration_amd import dist as D
-    from ddpm_image_restoration_amd import harness, spec, synth
+    from ddpm_image_restoration_amd import _lib, harness, spec, synth
     from ddpm_image_restoration_amd.model import MODEL_BY_ARCH
     from ddpm_image_restoration_amd.sampler import SAMPLER_BY_ARCH
 
@@ -170,7 +173,8 @@ def run_workload(w: dict, env, dev, K: int, W: int, full: bool = False, graph: i
     c_ms, c_n, _ = model.profile_read("codec_host")
     _, g_taken, g_total = model.profile_read("attention_general")
     det = {"ms_per_step": ms_per_step, "steps_timed": steps_timed, "warmup": W, "n_total": n_total, "load_s": load_s,
-           "dev_codec": dev_codec, "version": model.version(), "weight_blob_bytes": model.weight_blob_bytes()}
+           "dev_codec": dev_codec, "version": model.version(), "weight_blob_bytes": model.weight_blob_bytes(),
+           "codec_threads": (None if dev_codec else int(_lib.load().ddpmir_host_codec_threads()))}
     heads = 8 if arch_name == "avif" else 4
     peak = PEAK_TFLOPS[dtype]
     roof = None
@@ -181,8 +185,7 @@ def run_workload(w: dict, env, dev, K: int, W: int, full: bool = False, graph: i
                                            % (R * R, heads, 64 // heads),
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": traffic, "traffic_source": tsrc,
-                "binding_resource": ("priced against the bf16 MFMA peak as the contract asks; what the kernel saturates is VALU issue "
-                                     "(one v_exp_f32 per score: %d FLOP per exp), MFMA pipe ~35-40%% busy -- DESIGN.md 4.1" % (4 * 64 // heads)
+                "binding_resource": ("VALU issue (one v_exp_f32 per score, %d FLOP per exp); priced against the bf16 MFMA peak -- DESIGN.md 4.1" % (4 * 64 // heads)
                                      if dtype != "f32" else "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32 tiles)"),
                 "avg_launch_ms": a_ms / a_n, "launches": a_n, "forward_ms": (f_ms / f_n) if f_n else None}
     codec_obj = None
@@ -237,7 +240,7 @@ def run_workload(w: dict, env, dev, K: int, W: int, full: bool = False, graph: i
                "roofline": roof, "gemm_class": gemm if roof is None or roof.get("bf16_launches") is None else None,
                "attention_routing": ({"general_kernel_workgroups_with_work": g_taken, "general_kernel_workgroups_launched": int(g_total),
                                       "share_general": (g_taken / g_total) if g_total else None,
-                                      "meaning": "query blocks whose score bound max|q|*max|k| > 80 (log2) need the running-max kernel"}
+                                      "meaning": "query blocks whose score bound exceeds 80 (log2) take the running-max kernel"}
                                      if g_total else None),
                "codec": codec_obj}
     if w.get("reference_it_per_s"):
@@ -265,43 +268,196 @@ def run_workload(w: dict, env, dev, K: int, W: int, full: bool = False, graph: i
 
 
 EXTRA_WORKLOADS = [
-    dict(name="BASELINE configs[2] per-GPU shape: WebP 256x256, B=16, T=1000, q10 (host libwebp pool, two lanes)",
+    dict(id="c2_webp", name="BASELINE configs[2] per-GPU shape: WebP 256x256, B=16, T=1000, q10 (host libwebp pool, two lanes)",
          arch="webp", size=256, batch=16, T=1000, quality=10, attn="all", dtype="bf16", steps=5, warmup=2),
-    dict(name="BASELINE configs[3] per-GPU shape: AVIF 256x256, B=16, T=250, q10 (host libavif pool, two lanes)",
+    dict(id="c3_avif", name="BASELINE configs[3] per-GPU shape: AVIF 256x256, B=16, T=250, q10 (host libavif pool, two lanes)",
          arch="avif", size=256, batch=16, T=250, quality=10, attn="all", dtype="bf16", steps=4, warmup=2),
-    dict(name="BASELINE configs[4] shape in bf16 mode: JPEG 512x512, B=8, T=1000, q20, attention at the bottleneck only",
+    dict(id="c4_bf16", name="BASELINE configs[4] shape in bf16 mode: JPEG 512x512, B=8, T=1000, q20, attention at the bottleneck only",
          arch="jpeg", size=512, batch=8, T=1000, quality=20, attn="bottleneck", dtype="bf16", steps=10, warmup=3),
-    dict(name="BASELINE configs[4] shape in bf16 mode with the bf16 activation stream (option bf16_activation_stream = 1: tensors between "
-              "residual blocks stored as bf16, fp8 mode's default; opt-in in bf16 mode: forward error mean 2.0e-3 vs 1.7e-3, restored PSNR unchanged)",
+    dict(id="c4_bf16_s16", name="BASELINE configs[4] shape in bf16 mode with the bf16 activation stream (option bf16_activation_stream = 1: tensors between "
+                                "residual blocks stored as bf16, fp8 mode's default; opt-in in bf16 mode: forward error mean 2.0e-3 vs 1.7e-3, restored PSNR unchanged)",
          arch="jpeg", size=512, batch=8, T=1000, quality=20, attn="bottleneck", dtype="bf16", steps=10, warmup=3, stream16=1),
-    dict(name="BASELINE configs[4] shape, fp8 mode (e4m3 operands in the 3x3 convs with >= 256 channels)",
+    dict(id="c4_fp8", name="BASELINE configs[4] shape, fp8 mode (e4m3 operands in the 3x3 convs with >= 256 channels)",
          arch="jpeg", size=512, batch=8, T=1000, quality=20, attn="bottleneck", dtype="fp8", steps=10, warmup=3),
-    dict(name="BASELINE configs[4] shape, fp8 mode with e4m3 operands in every 3x3 conv with >= 64 channels (fp8_min_channels = 64; "
-              "restored PSNR -0.03 dB vs fp32 mode, forward error 2.1e-2 mean: profiles/r03_fp8_eval_configs4.txt)",
+    dict(id="c4_fp8_64", name="BASELINE configs[4] shape, fp8 mode with e4m3 operands in every 3x3 conv with >= 64 channels (fp8_min_channels = 64; "
+                              "parity fences: tests/test_gpu_fullsize.py::test_fp8_min_channels_model_level)",
          arch="jpeg", size=512, batch=8, T=1000, quality=20, attn="bottleneck", dtype="fp8", steps=10, warmup=3, fp8_min_channels=64),
-    dict(name="BASELINE configs[0] on the GPU: JPEG 32x32, B=4, T=50, q10, complete restoration (fp32 parity mode)",
+    dict(id="c0_f32", name="BASELINE configs[0] on the GPU: JPEG 32x32, B=4, T=50, q10, complete restoration (fp32 parity mode)",
          arch="jpeg", size=32, batch=4, T=50, quality=10, attn="all", dtype="f32", steps=45, warmup=5, cpu_sample_steps=5,
          reference_cpu_images_per_sec=0.364,
          reference_source="the reference's own PyTorch CPU path on this configuration: 10.98 s for the batch, 8 threads, survey container (BASELINE.md section 2)"),
-    dict(name="BASELINE configs[0] on the GPU, bf16 mode",
+    dict(id="c0_bf16", name="BASELINE configs[0] on the GPU, bf16 mode",
          arch="jpeg", size=32, batch=4, T=50, quality=10, attn="all", dtype="bf16", steps=45, warmup=5),
-    dict(name="reference notebook shape: JPEG 64x64, B=18, 80 steps (svd imagenet.ipynb c0 output: 18.2 it/s on the author's CUDA GPU)",
+    dict(id="nb_jpeg64", name="reference notebook shape: JPEG 64x64, B=18, 80 steps (svd imagenet.ipynb c0 output: 18.2 it/s on the author's CUDA GPU)",
          arch="jpeg", size=64, batch=18, T=80, quality=20, attn="all", dtype="bf16", steps=60, warmup=10,
          reference_it_per_s=18.2, reference_source="svd imagenet.ipynb c0 output (BASELINE.md section 1); unnamed CUDA GPU"),
-    dict(name="reference notebook shape: WebP 64x64, B=18, 80 steps (webp.ipynb c0 output: 16.2 it/s)",
+    dict(id="nb_webp64", name="reference notebook shape: WebP 64x64, B=18, 80 steps (webp.ipynb c0 output: 16.2 it/s)",
          arch="webp", size=64, batch=18, T=80, quality=20, attn="all", dtype="bf16", steps=60, warmup=10,
          reference_it_per_s=16.2, reference_source="webp.ipynb c0 output (BASELINE.md section 1); unnamed CUDA GPU"),
-    dict(name="reference notebook shape: JPEG 32x32, B=128, 80 steps (svd.ipynb c0 output: 13.8 it/s)",
+    dict(id="nb_jpeg32", name="reference notebook shape: JPEG 32x32, B=128, 80 steps (svd.ipynb c0 output: 13.8 it/s)",
          arch="jpeg", size=32, batch=128, T=80, quality=20, attn="all", dtype="bf16", steps=60, warmup=10,
          reference_it_per_s=13.8, reference_source="svd.ipynb c0 output (BASELINE.md section 1); unnamed CUDA GPU"),
-    dict(name="headline workload, worst case of the attention routing: no-max kernel disabled (every query block takes the "
-              "general running-max kernel, as with unbounded scores everywhere)",
+    dict(id="worst_attn", name="headline workload, worst case of the attention routing: no-max kernel disabled (every query block takes the "
+                               "general running-max kernel, as with unbounded scores everywhere)",
          arch="jpeg", size=256, batch=16, T=1000, quality=10, attn="all", dtype="bf16", steps=4, warmup=1, nm_bound=-1.0,
          note="general_kernel_only"),
 ]
 
+LINE_LIMIT = 6000          # characters of the final stdout line (the driver's tail of stdout + stderr is 8 000)
+WORKLOADS_FILE = os.path.join(ROOT, "gpurun_out", "bench_workloads.json")
+# keys the line may lose, in this order, if it ever grows past LINE_LIMIT (the contract's keys are never dropped)
+OPTIONAL_KEYS = ["workloads_file", "codec", "attention_routing", "general_kernel_only", "workloads_summary", "distributed", "library"]
 
-def main():
+
+def summarise_workloads(extras: list) -> list:
+    """Compact form of the extra slices for the headline line: short id, ms per step, images/s, roofline fraction."""
+    out = []
+    for e in extras:
+        if "error" in e or "ms_per_step" not in e:
+            out.append({"id": e.get("id"), "error": str(e.get("error", "no result"))[:80]})
+            continue
+        roof = e.get("roofline") or {}
+        s = {"id": e.get("id"), "ms_per_step": round(e["ms_per_step"], 3), "images_per_sec": float("%.4g" % e["images_per_sec"]),
+             "roofline_frac": round(roof["frac"], 4) if roof.get("frac") is not None else None}
+        if e.get("reference_it_per_s"):
+            s["steps_per_sec"] = round(e["steps_per_sec"], 1)
+            s["reference_it_per_s"] = e["reference_it_per_s"]
+        out.append(s)
+    return out
+
+
+def fit_line(line: dict, limit: int = LINE_LIMIT) -> str:
+    """json.dumps(line), dropping optional keys (never the contract's) until it fits the driver's tail."""
+    line = dict(line)
+    txt = json.dumps(line)
+    for k in OPTIONAL_KEYS:
+        if len(txt) <= limit:
+            break
+        if line.pop(k, None) is not None:
+            line["dropped_for_length"] = line.get("dropped_for_length", []) + [k]
+            txt = json.dumps(line)
+    if len(txt) > limit:        # last resort: shorten the free-text fields
+        for obj in (line.get("config", {}), line.get("roofline") or {}, line.get("cpu_baseline") or {}):
+            for k, v in list(obj.items()):
+                if isinstance(v, str) and len(v) > 120:
+                    obj[k] = v[:117] + "..."
+        txt = json.dumps(line)
+    return txt
+
+
+def headline_line(args, env_world: int, backend: str | None, det: dict, local_world: int, codec_threads: int | None) -> dict:
+    """The contract's JSON object from the measured details of the headline workload (pure: no GPU, used by a CPU test too)."""
+    T, R, B, q = args.T, args.size, args.batch, args.quality
+    ms_per_step, steps_timed, n_total, dev_codec = det["ms_per_step"], det["steps_timed"], det["n_total"], det["dev_codec"]
+    cfg_no = {("jpeg", 1000): 1, ("webp", 1000): 2, ("avif", 250): 3}.get((args.arch, T))
+    is_named = cfg_no is not None and (R, B, q, args.attn, args.dtype) == (256, 16, 10, "all", "bf16")
+    codec_txt = ("device JPEG round trip (bit-exact to libjpeg-turbo)" if dev_codec else
+                 "host Pillow/libjpeg-turbo callback" if args.arch == "jpeg" else
+                 ("lib%s C-API thread pool (bit-identical to Pillow), two pipelined micro-batch lanes" % args.arch
+                  if args.host_codec == "native" else "callback into Pillow, two pipelined micro-batch lanes"))
+    line = {
+        "metric": "restored images/sec (%dx%d, T=%d)" % (R, R, T), "value": n_total / (T * ms_per_step / 1e3), "unit": "images/sec",
+        "n_gpus": env_world, "steps": steps_timed, "warmup": det["warmup"], "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": "%s: %s restoration U-Net, %dx%d, batch %d/GPU, T=%d, %s q%d; "
+                               "step = one reverse-diffusion timestep (U-Net forward + codec round trip + DDRM update)"
+                               % (("BASELINE configs[%d]%s" % (cfg_no, "" if cfg_no == 1 else " (per-GPU shape)")) if is_named
+                                  else "variant of BASELINE configs", args.arch.upper(), R, R, B, T, args.arch.upper(), q),
+                   "global_batch": n_total, "image": R, "T": T, "quality": q, "attn_levels": args.attn,
+                   "codec": codec_txt, "timestep_launch": "captured hipGraphs" if args.graph else "eager",
+                   "arithmetic": {"bf16": "bf16 MFMA operands, fp32 accumulation / softmax / GroupNorm statistics / residual stream; restored PSNR equals "
+                                          "fp32 mode's as a mean over an image set (tests/test_gpu_psnr256.py); 1e-3 pixel parity is fp32 mode's (--dtype f32)",
+                                  "fp8": "as bf16, with OCP e4m3 operands in the 3x3 convs with >= %d channels" % (args.fp8_min_channels or 256),
+                                  "f32": "fp32 matrix cores"}[args.dtype],
+                   "parallelism": f"dp{env_world} (independent image shards, no collective in the loop)"},
+        "library": det["version"],
+        "distributed": {"backend": backend if env_world > 1 else None, "world_size": env_world, "local_world_size": local_world,
+                        "codec_threads": codec_threads, "weight_blob_bytes": det["weight_blob_bytes"],
+                        "load_pack_broadcast_s": round(det["load_s"], 3)},
+    }
+    if det.get("codec"):
+        line["codec"] = det["codec"]
+    if det.get("roof"):
+        line["roofline"] = det["roof"]
+    if det.get("routing"):
+        line["attention_routing"] = det["routing"]
+    return line
+
+
+def workloads_child(args):
+    """Child process of the default N=1 run: the extra workload slices, one after the other, the full records rewritten to
+    `args.workloads_child` after every slice (so whatever was measured survives a fault in a later one)."""
+    import torch
+    from ddpm_image_restoration_amd import dist as D
+    env = D.DistEnv(0, 1, 0, "none")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    sel = [int(i) for i in args.workloads.split(",")] if args.workloads else range(len(EXTRA_WORKLOADS))
+    extras = []
+    for i in sel:
+        w = EXTRA_WORKLOADS[i]
+        t0 = time.perf_counter()
+        try:
+            s, _ = run_workload(w, env, dev, w["steps"], w["warmup"])
+            s["id"] = w["id"]
+        except Exception as e:
+            s = {"id": w["id"], "name": w["name"], "error": repr(e)[:300]}
+        s["wall_s"] = round(time.perf_counter() - t0, 2)
+        extras.append(s)
+        tmp = args.workloads_child + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump({"workloads": extras}, f, indent=1)
+        os.replace(tmp, args.workloads_child)
+
+
+def run_children(args, line: dict, extra_workloads: bool, cpu: bool):
+    """The two child processes of the N=1 run, started only after the headline has been measured and the parent's model freed:
+    (1) the extra workload slices on the GPU, (2) the numpy oracle on the host cores.  Their output never reaches this process's
+    stdout / stderr (captured into gpurun_out/), so nothing but the final line is printed."""
+    import subprocess
+    me = os.path.abspath(__file__)
+    os.makedirs(os.path.dirname(WORKLOADS_FILE), exist_ok=True)
+    if extra_workloads:
+        try:
+            os.remove(WORKLOADS_FILE)
+        except OSError:
+            pass
+        cmd = [sys.executable, me, "--workloads-child", WORKLOADS_FILE] + (["--workloads", args.workloads] if args.workloads else [])
+        rc, note = None, None
+        try:
+            with open(WORKLOADS_FILE + ".log", "w") as log:
+                rc = subprocess.run(cmd, stdout=log, stderr=subprocess.STDOUT, timeout=900).returncode
+        except Exception as e:
+            note = "%r" % (e,)
+        extras = []
+        try:
+            extras = json.load(open(WORKLOADS_FILE))["workloads"]
+        except Exception:
+            pass
+        line["workloads_summary"] = summarise_workloads(extras)
+        line["workloads_file"] = {"path": os.path.relpath(WORKLOADS_FILE, ROOT), "child_rc": rc, "slices": len(extras)}
+        if note:
+            line["workloads_file"]["note"] = note[:120]
+        worst = next((e for e in extras if e.get("note") == "general_kernel_only" and "ms_per_step" in e), None)
+        if worst:
+            line["general_kernel_only"] = {"ms_per_step": worst["ms_per_step"], "images_per_sec": worst["images_per_sec"],
+                                           "meaning": "same workload, every query block routed to the general (running-max) attention kernel"}
+    if cpu:
+        # a failure of the host-side numpy / BLAS stack must not take the measured line with it
+        try:
+            r = subprocess.run([sys.executable, me, "--cpu-baseline-only", "--size", str(args.size), "--quality", str(args.quality),
+                                "--arch", args.arch, "--T", str(args.T)], capture_output=True, text=True, timeout=600)
+            out = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            line["cpu_baseline"] = json.loads(out[-1]) if (r.returncode == 0 and out) else \
+                {"value": None, "unit": "images/sec", "cores": 0, "kind": "port",
+                 "sample": "cpu baseline process failed (rc %d): %s" % (r.returncode, r.stderr.strip()[-200:])}
+        except Exception as e:  # timeout etc.
+            line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port",
+                                    "sample": "cpu baseline not measured: %r" % (e,)}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -324,11 +480,19 @@ def main():
     ap.add_argument("--full", action="store_true", help="time one complete T-step restoration instead of a slice")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-steps", action="store_true", help=argparse.SUPPRESS)   # child: honour --steps / --batch for the oracle sample
-    args = ap.parse_args()
+    ap.add_argument("--workloads-child", default=None, help=argparse.SUPPRESS)    # child: run the extra slices, write this file
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
     T = args.T
     if args.cpu_baseline_only:      # child process of the N=1 run: numpy oracle only, never touches the GPU
         print(json.dumps(cpu_baseline(args.arch, args.size, args.quality, T, n_steps=max(1, args.steps if args.cpu_steps else 1),
                                       batch=args.batch if args.cpu_steps else 1)), flush=True)
+        return
+    if args.workloads_child:
+        workloads_child(args)
         return
 
     import torch
@@ -346,79 +510,16 @@ def main():
     K, W = max(1, args.steps), max(0, args.warmup)
     summ, det = run_workload(head, env, dev, K, W, full=args.full, graph=args.graph, host_codec=args.host_codec, codec=args.codec,
                              detail_pass=(args.attn == "bottleneck"))
-    ms_per_step, steps_timed, n_total, dev_codec = det["ms_per_step"], det["steps_timed"], det["n_total"], det["dev_codec"]
-    value = n_total / (T * ms_per_step / 1e3)
     is_default = (args.arch, T, R, B, q, args.attn, args.dtype, args.graph, args.codec, args.full) == \
                  ("jpeg", 1000, 256, 16, 10, "all", "bf16", 0, None, False)
-
+    D.barrier(env)
     if env.rank == 0:
-        cfg_no = {("jpeg", 1000): 1, ("webp", 1000): 2, ("avif", 250): 3}.get((args.arch, T))
-        is_named = cfg_no is not None and (R, B, q, args.attn, args.dtype) == (256, 16, 10, "all", "bf16")
-        codec_txt = ("device JPEG round trip (bit-exact to libjpeg-turbo)" if dev_codec else
-                     "host Pillow/libjpeg-turbo callback" if args.arch == "jpeg" else
-                     ("library's lib%s C-API thread pool (bit-identical to Pillow), two pipelined micro-batch lanes (full-resolution blocks per lane, the levels below once per timestep)" % args.arch
-                      if args.host_codec == "native" else "callback into Pillow (the reference's own calls), two pipelined micro-batch lanes"))
-        line = {
-            "metric": "restored images/sec (%dx%d, T=%d)" % (R, R, T), "value": value, "unit": "images/sec",
-            "n_gpus": env.world, "steps": steps_timed, "warmup": det["warmup"], "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {"workload": "%s: %s restoration U-Net, %dx%d, batch %d/GPU, T=%d, %s q%d; "
-                                   "step = one reverse-diffusion timestep (U-Net forward + codec round trip + DDRM update)"
-                                   % (("BASELINE configs[%d]%s" % (cfg_no, "" if cfg_no == 1 else " (per-GPU shape)")) if is_named
-                                      else "variant of BASELINE configs", args.arch.upper(), R, R, B, T, args.arch.upper(), q),
-                       "global_batch": n_total, "image": R, "T": T, "quality": q, "attn_levels": args.attn,
-                       "codec": codec_txt, "timestep_launch": "captured hipGraphs" if args.graph else "eager",
-                       "arithmetic": {"bf16": "bf16 matrix-core operands, fp32 accumulation/softmax/GroupNorm statistics, fp32 residual stream; "
-                                              "parity of this mode: forward within 2e-2 max / 2e-3 mean of the reference, restored PSNR equal to "
-                                              "fp32 mode's as a MEAN over an image set within its standard error (per-image scatter of the chaotic loop: "
-                                              "<= 0.04 dB at 256x256, tests/test_gpu_psnr256.py); bit-level 1e-3 parity is fp32 mode's (--dtype f32)",
-                                      "fp8": "as bf16, with OCP e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4) in the 3x3 convs with >= %d channels" % (args.fp8_min_channels or 256),
-                                      "f32": "fp32 matrix cores"}[args.dtype],
-                       "parallelism": f"dp{env.world} (independent image shards, no collective in the loop)"},
-            "library": det["version"],
-            "distributed": {"backend": env.backend if env.world > 1 else None, "world_size": env.world,
-                            "weight_blob_bytes": det["weight_blob_bytes"],
-                            "load_pack_broadcast_s": det["load_s"]},
-        }
-        if det["codec"]:
-            line["codec"] = det["codec"]
-        if det["roof"]:
-            line["roofline"] = det["roof"]
-        if det["routing"]:
-            line["attention_routing"] = det["routing"]
-    # extra workload slices: N=1, default headline only (every rank would have to take part otherwise)
-    if env.world == 1 and is_default and not args.no_workloads:
-        extras = []
-        sel = [int(i) for i in args.workloads.split(",")] if args.workloads else range(len(EXTRA_WORKLOADS))
-        for i in sel:
-            w = EXTRA_WORKLOADS[i]
-            print(f"[bench] workload {i}: {w['name']}", file=sys.stderr, flush=True)
-            try:
-                s, _ = run_workload(w, env, dev, w["steps"], w["warmup"])
-                extras.append(s)
-            except Exception as e:   # a failing slice must not take the measured headline with it
-                extras.append({"name": w["name"], "error": repr(e)[:300]})
-        line["workloads"] = extras
-        worst = next((e for e in extras if e.get("note") == "general_kernel_only" and "ms_per_step" in e), None)
-        if worst:
-            line["general_kernel_only"] = {"ms_per_step": worst["ms_per_step"], "images_per_sec": worst["images_per_sec"],
-                                           "meaning": "the same workload with every query block routed to the general (running-max) attention kernel"}
-    if env.rank == 0:
-        if not args.no_cpu_baseline and env.world == 1:     # the CPU baseline is timed at N=1 only
-            # in a child process: a failure of the host-side numpy / BLAS stack must not take the measured line with it
-            import subprocess
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(R),
-                                    "--quality", str(q), "--arch", args.arch, "--T", str(T)], capture_output=True, text=True, timeout=600)
-                out = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                line["cpu_baseline"] = json.loads(out[-1]) if (r.returncode == 0 and out) else \
-                    {"value": None, "unit": "images/sec", "cores": 0, "kind": "port",
-                     "sample": "cpu baseline process failed (rc %d): %s" % (r.returncode, r.stderr.strip()[-200:])}
-            except Exception as e:  # timeout etc.
-                line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port",
-                                        "sample": "cpu baseline not measured: %r" % (e,)}
-        print(json.dumps(line), flush=True)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(env.world)))
+        line = headline_line(args, env.world, env.backend, det, local_world, det.get("codec_threads"))
+        if env.world == 1:   # children only at N=1 (every rank would have to take part otherwise), after the headline is measured
+            torch.cuda.empty_cache()
+            run_children(args, line, extra_workloads=(is_default and not args.no_workloads), cpu=not args.no_cpu_baseline)
+        print(fit_line(line), flush=True)
     D.barrier(env)
     if env.world > 1:
         import torch.distributed as dist

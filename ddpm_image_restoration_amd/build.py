@@ -67,37 +67,60 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
     return _build(LIB, os.path.join(HERE, "build"), [], verbose)
 
 
+def _file_sha(path: str) -> str:
+    import hashlib
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
 def _build(lib: str, objdir: str, defines, verbose: bool) -> str:
+    import json
     hipcc = _hipcc()
+    hipcc_ver = _hipcc_version(hipcc)
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []
-    # incremental: an object is kept while it is newer than its source, every header and this script
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    # incremental by CONTENT, not mtime (a source restored with an old mtime, or a compiler upgrade, must not leave a stale
+    # object behind a fresh ddpmir_version() string): an object is kept while the sidecar next to it records the same source
+    # hash, header hash, flags and hipcc version
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     hdrs += [os.path.join(HERE, "..", "include", f) for f in ("ddpmir.h", "ddpmir_ops.h")] + [os.path.abspath(__file__)]
-    t_hdr = max(os.path.getmtime(h) for h in hdrs)
+    hdr_sha = "".join(_file_sha(h) for h in hdrs)
+    stamps = {}
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        if src != "api.hip" and os.path.exists(obj) and os.path.getmtime(obj) > max(t_hdr, os.path.getmtime(os.path.join(CSRC, src))):
-            continue
         extra = ["-ffp-contract=off"] if src in NO_CONTRACT else []
         if src == "api.hip":   # ddpmir_version(): source hash + compiler version, so a stale prebuilt binary is detectable
-            extra += ['-DDDPMIR_SRC_HASH="%s"' % source_hash(), '-DDDPMIR_HIPCC_VERSION="%s"' % _hipcc_version(hipcc)]
+            extra += ['-DDDPMIR_SRC_HASH="%s"' % source_hash(), '-DDDPMIR_HIPCC_VERSION="%s"' % hipcc_ver]
         if src in VGPR_MFMA:
             extra += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
         if src in NO_SLP:
             extra += ["-fno-slp-vectorize"]
+        stamp = {"src": _file_sha(os.path.join(CSRC, src)), "hdr": hdr_sha, "flags": [*FLAGS, *defines, *extra], "hipcc": hipcc_ver}
+        stamps[obj] = stamp
+        try:
+            if os.path.exists(obj) and json.load(open(obj + ".stamp")) == stamp:
+                continue
+        except Exception:
+            pass
+        try:
+            os.remove(obj + ".stamp")
+        except OSError:
+            pass
         cmd = [hipcc, *FLAGS, *defines, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
-    for src, p in procs:
+    for src, obj, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             failed = True
             sys.stderr.write(f"--- {src} ---\n{out}\n")
-        elif verbose and out.strip():
-            sys.stderr.write(f"--- {src} ---\n{out}\n")
+        else:
+            with open(obj + ".stamp", "w") as fh:
+                json.dump(stamps[obj], fh)
+            if verbose and out.strip():
+                sys.stderr.write(f"--- {src} ---\n{out}\n")
     if failed:
         raise RuntimeError("hipcc failed")
     subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib, *objs, "-ldl", "-lpthread"])

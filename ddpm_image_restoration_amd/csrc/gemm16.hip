@@ -213,8 +213,12 @@ __device__ __forceinline__ void gemm16_epilogue(const IGemm& p, f32x16 (&acc)[NT
         v.x += (float)t[0]; v.y += (float)t[1]; v.z += (float)t[2]; v.w += (float)t[3];
       }
       if (p.gn_sums) {
-        gs1 += (v.x + v.y) + (v.z + v.w);
-        gs2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        // the sums are those of the values the consumer will normalise: where the result only exists as bf16, of the rounded
+        // values (as head_mix16_k and stream_k do)
+        float4 u = v;
+        if (out16 && !p.out) { u.x = (float)(__bf16)v.x; u.y = (float)(__bf16)v.y; u.z = (float)(__bf16)v.z; u.w = (float)(__bf16)v.w; }
+        gs1 += (u.x + u.y) + (u.z + u.w);
+        gs2 += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
       }
       if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + no) = v;
       if (out16) {

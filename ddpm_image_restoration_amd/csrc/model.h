@@ -135,18 +135,31 @@ class Context {
  private:
   // ---- weights
   std::map<std::string, HostTensor> host_;
-  std::vector<BlockW> blocks_;
-  TimeEmbedW tw_{};
-  float *head_g_ = nullptr, *head_b_ = nullptr, *head_dct_ = nullptr;
-  AvifTransformW head_at_;
-  ConvW head_conv_;
+  // The weight pointer table.  layout_weights() fills the table it is HANDED: the sizing pass (weight_blob_bytes) lays out a
+  // scratch table over a base-less arena, finalize_weights lays out wt_ over the real blob -- so no dry run can ever re-point
+  // the live table at NULL + offset (the round-3 memory-access fault).
+  struct Weights {
+    std::vector<BlockW> blocks;
+    TimeEmbedW tw{};
+    float *head_g = nullptr, *head_b = nullptr, *head_dct = nullptr;
+    AvifTransformW head_at;
+    ConvW head_conv;
+    int64_t n_params = 0;
+    int nt_total = 0;
+  } wt_;
+  std::vector<BlockW>& blocks_ = wt_.blocks;
+  TimeEmbedW& tw_ = wt_.tw;
+  float *&head_g_ = wt_.head_g, *&head_b_ = wt_.head_b, *&head_dct_ = wt_.head_dct;
+  AvifTransformW& head_at_ = wt_.head_at;
+  ConvW& head_conv_ = wt_.head_conv;
+  int64_t& n_params_ = wt_.n_params;
+  int& nt_total_ = wt_.nt_total;
   char* wblob_ = nullptr;
   bool wblob_owned_ = false;
   bool finalized_ = false;
-  int64_t n_params_ = 0;
-  int nt_total_ = 0;
-  size_t blob_bytes_ = 0;          // packed blob size, measured once (weight_blob_bytes)
-  void layout_weights(Arena& a, bool upload);
+  int64_t layout_params_ = 0;      // scratch counter of the layout pass in progress (put / put_conv), copied into its table at the end
+  size_t blob_bytes_ = 0;          // packed blob size, measured once per configuration (weight_blob_bytes)
+  void layout_weights(Arena& a, bool upload, Weights& w);
   void put(Arena& a, bool upload, float*& dst, const std::string& name, size_t expect);
   void put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name, int cout, int cin, int ksz);
   void put_gate_pair(Arena& a, bool upload, BlockW& b, const std::string& fg);
@@ -190,8 +203,10 @@ class Context {
     float *g_x = nullptr, *g_t = nullptr, *g_cl = nullptr, *g_out = nullptr;
   } plan_;
   void ensure_plan(int B, int H, int W);
-  void layout_plan(Arena& a, int B, int H, int W);
+  // fills the plan it is handed (ensure_plan sizes with a scratch Plan over a base-less arena, then lays out plan_ over the allocation)
+  void layout_plan(Arena& a, Plan& p, int B, int H, int W) const;
   void free_plan();
+  void order_after_caller();   // stream_ waits for what the caller enqueued on the default stream
 
   void forward(const float* x, const float* t, const float* cl, float* out, hipStream_t s);
   // forward() in three pieces (model.hip): the full-resolution blocks per row range, the levels below for the whole batch

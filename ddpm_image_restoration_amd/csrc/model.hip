@@ -65,6 +65,7 @@ Context::Context(const ddpmir_config& c) : cfg(c), k(consts_for(c.arch)) {
   DDPMIR_HIP_CHECK(hipEventCreateWithFlags(&lane_ev_[1], hipEventDisableTiming));
   DDPMIR_HIP_CHECK(hipMalloc(&attn_general_taken_, 16));
   DDPMIR_HIP_CHECK(hipMemset(attn_general_taken_, 0, 16));
+  for (auto& d : kBlocks) wt_.nt_total += d.cout;   // configuration constant: a plan made before the weights exist sizes tproj from it
 }
 
 Context::~Context() {
@@ -93,7 +94,7 @@ void Context::load_tensor(const std::string& name, const float* data, const int6
 
 void Context::put(Arena& a, bool upload, float*& dst, const std::string& name, size_t expect) {
   dst = a.take<float>(expect);
-  if (name.find("dct_matrix") == std::string::npos) n_params_ += (int64_t)expect;
+  if (name.find("dct_matrix") == std::string::npos) layout_params_ += (int64_t)expect;
   if (!upload) return;
   auto it = host_.find(name);
   if (it == host_.end()) throw std::runtime_error("missing tensor in state dict: " + name);
@@ -117,7 +118,7 @@ void Context::put_conv(Arena& a, bool upload, ConvW& cw, const std::string& name
   cw.is_f8 = f8;
   cw.w8 = f8 ? a.take<unsigned char>(n16) : nullptr;
   cw.w8_inv_dev = f8 ? a.take<float>(1) : nullptr;
-  n_params_ += (int64_t)cout * cin * cw.taps + cout;
+  layout_params_ += (int64_t)cout * cin * cw.taps + cout;
   if (!upload) return;
   auto iw = host_.find(name + ".weight");
   if (iw == host_.end()) iw = host_.find(name + "_weight");   // attn.in_proj_weight
@@ -212,24 +213,26 @@ void Context::put_gate_pair(Arena& a, bool upload, BlockW& b, const std::string&
   DDPMIR_HIP_CHECK(hipMemcpy(b.fg2.b, b2v.data(), b2v.size() * 4, hipMemcpyHostToDevice));
 }
 
-void Context::layout_weights(Arena& a, bool up) {
-  n_params_ = 0;
-  blocks_.assign(13, BlockW());
+void Context::layout_weights(Arena& a, bool up, Weights& w) {
+  // every pointer goes into the table `w` the caller handed in -- never through the members (see model.h)
+  layout_params_ = 0;
+  auto& blocks = w.blocks;
+  blocks.assign(13, BlockW());
   float *w0, *b0, *w2, *b2;
   put(a, up, w0, "time_embed.proj.0.weight", 1024 * 256);
   put(a, up, b0, "time_embed.proj.0.bias", 1024);
   put(a, up, w2, "time_embed.proj.2.weight", 256 * 1024);
   put(a, up, b2, "time_embed.proj.2.bias", 256);
-  nt_total_ = 0;
-  for (auto& d : kBlocks) nt_total_ += d.cout;
-  float* wt = a.take<float>((size_t)nt_total_ * 256);
-  float* bt = a.take<float>(nt_total_);
-  tw_ = TimeEmbedW{w0, b0, w2, b2, wt, bt, nt_total_};
+  w.nt_total = 0;
+  for (auto& d : kBlocks) w.nt_total += d.cout;
+  float* wt = a.take<float>((size_t)w.nt_total * 256);
+  float* bt = a.take<float>(w.nt_total);
+  w.tw = TimeEmbedW{w0, b0, w2, b2, wt, bt, w.nt_total};
   int off = 0;
   const bool avif = cfg.arch == DDPMIR_ARCH_AVIF;
   for (int i = 0; i < 13; ++i) {
     const BlockDef& d = kBlocks[i];
-    BlockW& b = blocks_[i];
+    BlockW& b = blocks[i];
     const std::string n = d.name;
     b.name = n; b.cin = d.cin; b.cinp = round_up(d.cin, 4); b.cout = d.cout; b.level = d.level;
     b.has_shortcut = d.cin != d.cout;
@@ -245,7 +248,7 @@ void Context::layout_weights(Arena& a, bool up) {
       DDPMIR_HIP_CHECK(hipMemcpy(wt + (size_t)off * 256, iw->second.data.data(), (size_t)d.cout * 256 * 4, hipMemcpyHostToDevice));
       DDPMIR_HIP_CHECK(hipMemcpy(bt + off, ib->second.data.data(), (size_t)d.cout * 4, hipMemcpyHostToDevice));
     }
-    n_params_ += (int64_t)d.cout * 257;
+    layout_params_ += (int64_t)d.cout * 257;
     off += d.cout;
     put(a, up, b.n2g, n + ".norm2.weight", d.cout);
     put(a, up, b.n2b, n + ".norm2.bias", d.cout);
@@ -258,7 +261,7 @@ void Context::layout_weights(Arena& a, bool up) {
       // inverse_weights is a parameter the forward never reads (avif_inference.py:130): validated and counted only
       if (up && host_.find(fg + ".adaptive_transform.inverse_weights") == host_.end())
         throw std::runtime_error("missing tensor in state dict: " + fg + ".adaptive_transform.inverse_weights");
-      n_params_ += (int64_t)d.cout * 64;
+      layout_params_ += (int64_t)d.cout * 64;
       put_conv(a, up, b.at.q0, fg + ".adaptive_transform.quantization.0", d.cout, d.cout, 1);
       put_conv(a, up, b.at.q2, fg + ".adaptive_transform.quantization.2", d.cout, d.cout, 1);
       for (int s = 0; s < 4; ++s) {
@@ -308,31 +311,33 @@ void Context::layout_weights(Arena& a, bool up) {
     }
   }
   if (avif) {
-    put(a, up, head_at_.tw, "avif_layer.transform_weights", 64 * 64);
+    put(a, up, w.head_at.tw, "avif_layer.transform_weights", 64 * 64);
     if (up && host_.find("avif_layer.inverse_weights") == host_.end())
       throw std::runtime_error("missing tensor in state dict: avif_layer.inverse_weights");
-    n_params_ += 64 * 64;
-    put_conv(a, up, head_at_.q0, "avif_layer.quantization.0", 64, 64, 1);
-    put_conv(a, up, head_at_.q2, "avif_layer.quantization.2", 64, 64, 1);
+    layout_params_ += 64 * 64;
+    put_conv(a, up, w.head_at.q0, "avif_layer.quantization.0", 64, 64, 1);
+    put_conv(a, up, w.head_at.q2, "avif_layer.quantization.2", 64, 64, 1);
   } else {
-    put(a, up, head_dct_, "dct_layer.dct_matrix", (size_t)k.dct_block * k.dct_block);
+    put(a, up, w.head_dct, "dct_layer.dct_matrix", (size_t)k.dct_block * k.dct_block);
   }
-  put(a, up, head_g_, "out_conv.0.weight", 64);
-  put(a, up, head_b_, "out_conv.0.bias", 64);
-  put_conv(a, up, head_conv_, "out_conv.2", 3, 64, 3);
+  put(a, up, w.head_g, "out_conv.0.weight", 64);
+  put(a, up, w.head_b, "out_conv.0.bias", 64);
+  put_conv(a, up, w.head_conv, "out_conv.2", 3, 64, 3);
+  w.n_params = layout_params_;
 }
 
 size_t Context::weight_blob_bytes() {
-  // The size comes from a DRY RUN of layout_weights (no base address), which re-points every weight pointer of the context
-  // at offsets from NULL.  That is harmless before finalize_weights (which lays them out again over the real blob) and was
-  // a latent fault after it: a later forward read its weights from addresses like 0x31000 ("Memory access fault by GPU ...
-  // on address 0x31000", round 3; bench.py asked for the blob size between two sampling calls).  The layout only depends on
-  // the configuration, so it is measured once and cached; after finalize the pointers are never touched again.
+  // The size comes from a DRY RUN of layout_weights over an arena with no base address.  Until round 3 that dry run wrote the
+  // context's own pointer table, i.e. re-pointed every weight at NULL + offset: harmless before finalize_weights, a memory
+  // access fault after it ("... on address 0x31000": bench.py asked for the blob size between two sampling calls).  Now the
+  // dry run fills a scratch table that is thrown away, so a size query can never touch the live one, before or after
+  // finalize; the size is still cached per configuration (set_option("fp8_min_channels") resets it).
   if (blob_bytes_ == 0) {
-    if (finalized_) throw std::logic_error("weight_blob_bytes: layout was not measured before finalize_weights");
+    Weights scratch;
     Arena a;
-    layout_weights(a, false);
+    layout_weights(a, false, scratch);
     blob_bytes_ = (a.off + 255) & ~size_t(255);
+    if (!finalized_) wt_.n_params = scratch.n_params;   // param_count() before the weights are loaded
   }
   return blob_bytes_;
 }
@@ -340,6 +345,7 @@ size_t Context::weight_blob_bytes() {
 void Context::finalize_weights(void* dev_blob, int fill) {
   if (finalized_) throw std::logic_error("finalize_weights called twice on one context");
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
+  free_plan();   // a workspace planned before the weights existed (jpeg_roundtrip / phase_consistency) is re-planned on first use
   const size_t bytes = weight_blob_bytes();
   if (dev_blob) {
     wblob_ = static_cast<char*>(dev_blob);
@@ -352,7 +358,7 @@ void Context::finalize_weights(void* dev_blob, int fill) {
   Arena a;
   a.base = wblob_;
   if (fill) DDPMIR_HIP_CHECK(hipMemset(wblob_, 0, bytes));
-  layout_weights(a, fill != 0);
+  layout_weights(a, fill != 0, wt_);
   DDPMIR_HIP_CHECK(hipDeviceSynchronize());
   if (cfg.dtype == DDPMIR_FP8)   // the fp8 weight scales travel inside the blob (adopted blobs carry them too)
     for (auto& b : blocks_)
@@ -363,8 +369,7 @@ void Context::finalize_weights(void* dev_blob, int fill) {
 }
 
 // ------------------------------------------------------------------------------------------------ workspace
-void Context::layout_plan(Arena& a, int B, int H, int W) {
-  Plan& p = plan_;
+void Context::layout_plan(Arena& a, Plan& p, int B, int H, int W) const {
   const bool avif = cfg.arch == DDPMIR_ARCH_AVIF;
   auto hw = [&](int lvl) { return (size_t)(H >> lvl) * (W >> lvl); };
   const size_t M0 = (size_t)B * H * W;
@@ -458,14 +463,18 @@ void Context::ensure_plan(int B, int H, int W) {
     throw std::invalid_argument("image size must be a positive multiple of 32 (five 2x2 pools)");
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
   free_plan();
-  Arena dry;
-  layout_plan(dry, B, H, W);
-  size_t bytes = (dry.off + 255) & ~size_t(255);
+  size_t bytes;
+  {   // sizing pass: a scratch Plan over a base-less arena -- plan_ stays empty until it can be laid out over real memory
+    Plan scratch;
+    Arena dry;
+    layout_plan(dry, scratch, B, H, W);
+    bytes = (dry.off + 255) & ~size_t(255);
+  }
   char* base = nullptr;
   DDPMIR_HIP_CHECK(hipMalloc(&base, bytes));
   DDPMIR_HIP_CHECK(hipMemset(base, 0, bytes));
   Arena a; a.base = base;
-  layout_plan(a, B, H, W);
+  layout_plan(a, plan_, B, H, W);
   plan_.base = base; plan_.bytes = bytes; plan_.B = B; plan_.H = H; plan_.W = W;
   fb_ = B;
   // DFT twiddles (double precision on the host, rounded once)
@@ -601,6 +610,7 @@ void Context::set_option(const std::string& name, double value) {
     if (value != 64 && value != 128 && value != 256) throw std::invalid_argument("fp8_min_channels must be 64, 128 or 256");
     fp8_min_ch_ = (int)value;
     blob_bytes_ = 0;
+    free_plan();   // the plan sizes a8 / S8 from this option, and ensure_plan is reachable before finalize (jpeg_roundtrip, phase_consistency)
     return;
   }
   if (name == "bf16_activation_stream") {   // -1: fp8 mode only (default); 0: never; 1: bf16 mode too.  Re-plans (buffers change type)
@@ -1153,6 +1163,14 @@ void Context::forward(const float* x, const float* t, const float* cl, float* ou
   fb_ = B;
 }
 
+// Every entry point that reads caller device buffers on the context's own stream calls this first: the caller produced them on
+// ITS stream -- the default stream, since the C ABI passes none -- and stream_ is non-blocking (no implicit ordering against
+// the default stream), so the order is made explicit with an event (a C caller that did not device-synchronise would race).
+void Context::order_after_caller() {
+  DDPMIR_HIP_CHECK(hipEventRecord(lane_ev_[0], nullptr));
+  DDPMIR_HIP_CHECK(hipStreamWaitEvent(stream_, lane_ev_[0], 0));
+}
+
 void Context::predict(const float* x, const float* t, const float* cl, float* out, int B, int H, int W, hipStream_t s) {
   if (!finalized_) throw std::logic_error("predict before finalize_weights");
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
@@ -1160,12 +1178,7 @@ void Context::predict(const float* x, const float* t, const float* cl, float* ou
   fb_ = B;
   const bool own = (s == nullptr);
   hipStream_t st = own ? stream_ : s;
-  if (own) {
-    // the caller's inputs were produced on ITS stream -- the default stream when NULL was passed -- and the context's stream
-    // is non-blocking (no implicit ordering against the default stream): order it explicitly
-    DDPMIR_HIP_CHECK(hipEventRecord(lane_ev_[0], nullptr));
-    DDPMIR_HIP_CHECK(hipStreamWaitEvent(st, lane_ev_[0], 0));
-  }
+  if (own) order_after_caller();
   Plan& p = plan_;
   const size_t n_img = (size_t)B * 3 * H * W;
   if (cfg.use_graph && !prof_on_) {
@@ -1216,6 +1229,7 @@ void Context::phase_fix(float* x, int B, int H, int W, double alpha, hipStream_t
 void Context::phase_consistency(const float* x, const float* ref, float* out, int B, int H, int W, double alpha) {
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
   ensure_plan(B, H, W);
+  order_after_caller();
   Plan& p = plan_;
   const size_t n = (size_t)B * 3 * H * W;
   phase_prepare(ref, B, H, W, stream_, 0);
@@ -1228,6 +1242,7 @@ void Context::phase_consistency(const float* x, const float* ref, float* out, in
 void Context::jpeg_roundtrip(const uint8_t* in, uint8_t* out, int B, int H, int W, int quality) {
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
   ensure_plan(B, H, W);
+  order_after_caller();
   launch_jpeg_roundtrip(in, out, plan_.s_jpeg, B, H, W, quality, stream_);
   DDPMIR_HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -1303,6 +1318,7 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
   }
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
   ensure_plan(B, H, W);
+  order_after_caller();   // y (and an injected noise tensor) come from the caller's stream
   Plan& p = plan_;
   hipStream_t s = stream_;
   const size_t n = (size_t)B * 3 * H * W;

@@ -857,7 +857,7 @@ int launch_stream(const void* in, int ldi, void* out, int ldo, int B, int Hi, in
     throw std::runtime_error("stream pass: channel count must be 16 bytes * 2^k (at most 256 lanes per pixel) with 16-byte aligned rows");
   int gl = 1;
   if (partial) {
-    if (!stream_stats_supported(C, G, (int)sizeof(T))) throw std::runtime_error("stream pass: a group must be 16 bytes * 2^k of channels, at most 8 groups");
+    if (!stream_stats_supported(C, G, (int)sizeof(T))) throw std::runtime_error("stream pass: a group must be 16 bytes * 2^k of channels (at most 64 lanes of 16 bytes), at most 8 groups");
     gl = C / G / N;
   }
   const int Ho = MODE == S16_POOL ? Hi / 2 : MODE == S16_UP ? 2 * Hi : Hi, Wo = MODE == S16_POOL ? Wi / 2 : MODE == S16_UP ? 2 * Wi : Wi;
@@ -876,7 +876,9 @@ bool stream_stats_supported(int C, int G, int elem_bytes) {
   const int N = 16 / elem_bytes;
   if (G < 1 || G > 8 || (C % G) != 0 || ((C / G) % N) != 0 || (C % N) != 0) return false;
   const int gl = C / G / N, CL = C / N;
-  return (gl & (gl - 1)) == 0 && (CL & (CL - 1)) == 0 && CL <= 256;
+  // gl <= 64: stream_k folds a group inside one wave (lanes with wslot % gl == 0 publish); a group spanning several waves
+  // (e.g. C = 1024, G = 1 in bf16) would lose the waves that hold slots 64 .. gl-1 -- not a shape the model has, so it is rejected
+  return (gl & (gl - 1)) == 0 && (CL & (CL - 1)) == 0 && CL <= 256 && gl <= 64;
 }
 int launch_stats16(const void* x16, int ldx, int B, int H, int W, int C, int G, double* partial, hipStream_t s) {
   return launch_stream<S16_STATS, __bf16>(x16, ldx, nullptr, 0, B, H, W, C, G, partial, s);

@@ -159,3 +159,108 @@ def test_fp8_mode_configs4(models):
     dd = psnr_each(r8) - psnr_each(r16)
     print(f"fp8 vs bf16 mode: forward max {e8.max():.3f} mean {e8.mean():.4f}; restored PSNR difference mean {dd.mean():+.4f} dB, std {dd.std():.4f}")
     assert abs(dd.mean()) < 0.05 and np.abs(dd).max() < 1.0
+
+
+# fp8_min_channels: forward-error fences against the fp32 oracle fixture (512 x 512, attention at the bottleneck) = 1.5 x the
+# values measured on MI355X (printed by the test; profiles/r04_fp8_min_channels_eval.txt), and the restored-PSNR bar of the mode
+# measured (round 4): 128: max 0.121, mean 9.9e-3;  64: max 0.206, mean 2.21e-2
+FP8_MIN_CH_FENCE = {128: (0.18, 1.5e-2), 64: (0.31, 3.3e-2)}
+
+
+@pytest.mark.parametrize("min_ch", [128, 64])
+def test_fp8_min_channels_model_level(min_ch, synth_state):
+    """Option fp8_min_channels = 128 / 64 (bench workload c4_fp8_64): e4m3 operands in every 3x3 conv with at least that many
+    input AND output channels.  The option re-sizes the weight blob, changes which producers write e4m3 operands
+    (gn_apply16_k, the gate epilogue, the split-K reduce, freq_gate_fused_k writing S as e4m3) and instantiates the F8 kernel
+    at 64 columns -- so it gets the model-level checks of the default fp8 mode: the oracle fixture within its own stated
+    fence, determinism, batch independence within the fence, a context growing 64 -> 512 pixels equal to fresh contexts, and
+    restored PSNR against bf16 mode."""
+    import torch
+    from ddpm_image_restoration_amd import harness
+    from ddpm_image_restoration_amd.model import JPEGDiffusionModel
+    from ddpm_image_restoration_amd.sampler import DDRMJPEGSampler
+    dev = torch.device("cuda", 0)
+    sd = synth_state(spec.ARCH_JPEG)
+
+    def make(dtype="fp8", mc=min_ch):
+        m = JPEGDiffusionModel(device=dev, dtype=dtype, attn_levels="bottleneck", fp8_min_channels=mc if dtype == "fp8" else None)
+        m.load_state_dict(sd)
+        return m
+    fmax, fmean = FP8_MIN_CH_FENCE[min_ch]
+    m8 = make()
+    m256 = make(mc=256)
+    assert m8.weight_blob_bytes() > m256.weight_blob_bytes()          # more e4m3 weight copies in the blob
+    del m256
+    g = np.load(os.path.join(GOLD, "jpeg_fwd512_bott_oracle.npz"))
+    s = int(g["stride"])
+    x = tt(synth.synth_images(1, 512, seed=int(g["seed_x"])))
+    y8 = m8(x, tt(g["t"]), tt(g["cl"]))
+    e8 = np.abs(y8.cpu().numpy()[:, :, ::s, ::s] - g["y"])
+    print(f"fp8_min_channels={min_ch}: forward 512x512 vs oracle max {e8.max():.4f} mean {e8.mean():.5f}")
+    assert e8.max() < fmax and e8.mean() < fmean, (e8.max(), e8.mean())
+    assert torch.equal(m8(x, tt(g["t"]), tt(g["cl"])), y8)                                   # deterministic
+    # growth 64 -> 512 -> 128 on one context == fresh contexts (the e4m3 operand buffers are re-planned with the option's sizes)
+    for size, batch in ((64, 2), (128, 2), (256, 2), (512, 1), (128, 3)):
+        xs = tt(synth.synth_images(batch, size, seed=70 + size))
+        ts = torch.full((batch,), 0.4, device="cuda")
+        fresh = make()
+        assert torch.equal(m8(xs, ts, ts), fresh(xs, ts, ts)), (min_ch, size)
+        del fresh
+    # batch independence within the fence
+    x2 = tt(synth.synth_images(2, 128, seed=5))
+    t2 = torch.tensor([0.2, 0.7], device="cuda")
+    y2 = m8(x2, t2, t2)
+    d = (m8(x2[1:], t2[1:], t2[1:]) - y2[1:]).abs()
+    assert float(d.max()) < fmax and float(d.mean()) < fmean
+    # restored PSNR against bf16 mode: 64 images, 64 x 64, JPEG q20, 80 steps
+    x0 = synth.synth_images(64, 64, seed=777)
+    yq = harness.COMPRESS[spec.ARCH_JPEG](torch.from_numpy(x0), 20).cuda()
+    r8 = DDRMJPEGSampler(m8).sample(yq, 20, steps=80, seed=5).cpu().numpy()
+    r16 = DDRMJPEGSampler(make("bf16")).sample(yq, 20, steps=80, seed=5).cpu().numpy()
+
+    def psnr_each(a):
+        a01, b01 = np.clip(a * 0.5 + 0.5, 0, 1), np.clip(x0 * 0.5 + 0.5, 0, 1)
+        return -10 * np.log10(((a01 - b01) ** 2).reshape(a.shape[0], -1).mean(axis=1) + 1e-8)
+    dd = psnr_each(r8) - psnr_each(r16)
+    print(f"fp8_min_channels={min_ch}: restored PSNR minus bf16 mode: mean {dd.mean():+.4f} dB, std {dd.std():.4f}, max |d| {np.abs(dd).max():.3f}")
+    assert abs(dd.mean()) < 0.08 and np.abs(dd).max() < 1.0
+
+
+def test_plan_made_before_the_weights_is_dropped_when_options_or_weights_change(synth_state):
+    """ddpmir_jpeg_roundtrip_u8 / ddpmir_phase_consistency plan the workspace without needing weights, so the
+    C-ABI order  jpeg_roundtrip(B,H,W) -> set_option(fp8_min_channels = 64) -> load -> finalize -> predict(same B,H,W)  used to
+    reuse a plan whose e4m3 operand buffers covered the >= 256-channel levels only (level-0 / 1 operands written ~8x past
+    them).  set_option now drops the plan, and so does finalize_weights.  Also: re-plans by option, blob-size queries and
+    forwards interleaved leave results bit-equal to a context that did none of that."""
+    import torch
+    from ddpm_image_restoration_amd.model import JPEGDiffusionModel
+    from ddpm_image_restoration_amd.sampler import jpeg_roundtrip_device
+    dev = torch.device("cuda", 0)
+    sd = synth_state(spec.ARCH_JPEG)
+    B, R = 2, 128
+    x = tt(synth.synth_images(B, R, seed=11))
+    t = torch.full((B,), 0.3, device="cuda")
+    ref = JPEGDiffusionModel(device=dev, dtype="fp8", attn_levels="bottleneck", fp8_min_channels=64)
+    ref.load_state_dict(sd)
+    want = ref(x, t, t)
+
+    m = JPEGDiffusionModel(device=dev, dtype="fp8", attn_levels="bottleneck")          # option still at its default (256)
+    u8 = (torch.rand(B, 3, R, R, device="cuda") * 255).to(torch.uint8)
+    jpeg_roundtrip_device(m, u8, 20)                                                           # plans (B, R, R) before any weight exists
+    n256 = m.weight_blob_bytes()
+    m.set_option("fp8_min_channels", 64)
+    assert m.weight_blob_bytes() > n256
+    jpeg_roundtrip_device(m, u8, 20)                                                           # plans again, now with the option's sizes
+    m.load_state_dict(sd)
+    assert torch.equal(m(x, t, t), want)
+    # interleave: size queries, re-planning options, other shapes, forwards
+    for k in range(3):
+        assert m.weight_blob_bytes() == ref.weight_blob_bytes()
+        m.set_option("bf16_activation_stream", 0)
+        y0 = m(x, t, t)
+        m.weight_blob_bytes()
+        m.set_option("bf16_activation_stream", -1)
+        jpeg_roundtrip_device(m, u8[:1, :, :64, :64].contiguous(), 10)
+        assert m.weight_blob_bytes() == ref.weight_blob_bytes()
+        assert torch.equal(m(x, t, t), want) and not torch.equal(y0, want)
+    assert m.param_count() == ref.param_count() > 1e8
