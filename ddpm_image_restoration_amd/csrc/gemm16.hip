@@ -21,233 +21,12 @@
 #include <cstdlib>
 
 #include "kernels.h"
-
-// IGemm::dbg (skip A loads / B loads / MFMAs / stores: the dissection runs of tools/gemm_inventory.py) only exists in
-// -DDDPMIR_EXPERIMENTS builds; in the shipped kernel the tests fold to constants.
-#ifdef DDPMIR_EXPERIMENTS
-#define GEMM_DBG(p) ((p).dbg)
-#else
-#define GEMM_DBG(p) 0
-#endif
+#include "gemm_epilogue.h"
 
 namespace ddpmir {
-
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
 namespace {
 
 constexpr int BM = 128;
-
-// Epilogue of the DMA GEMM kernels: split-K partial store, or accumulators -> wave-private LDS tile -> fused elementwise work
-// and row-contiguous stores (also the fused qkv packing and the GroupNorm statistics).  acc[nt][r] holds row
-// (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32 rows, column nt * 32 + lr.
-template <int NT>
-__device__ __forceinline__ void gemm16_epilogue(const IGemm& p, f32x16 (&acc)[NT], unsigned char* smem, int m0, int n0, int M, int HW,
-                                                int nsplit, int sk) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 31, lh = lane >> 5;
-  // ------------------------------------------------------------------------------------------ epilogue
-  if ((GEMM_DBG(p) & 8) && acc[0][0] != 12345.f) return;
-  const bool need_pos = p.tb || p.rowscale || p.epi_mask != MASK_NONE || p.sel_C;
-  const bool atomic = nsplit > 1;
-  if (atomic) {
-    // split-K: raw partial sums to the workspace slice of this split (128-byte row segments per wave instruction); the
-    // linear epilogue runs in splitk_reduce_k, which adds the slices in a fixed order
-    float* ws = p.splitk_ws + (size_t)sk * M * p.Cout;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= M) continue;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + nt * 32 + lr;
-        if (n < p.Cout) ws[(size_t)m * p.Cout + n] = acc[nt][r];
-      }
-    }
-    return;
-  }
-  // coalesced: accumulators -> wave-private LDS tile (HN column tiles at a time) -> 16-byte row-contiguous accesses
-  constexpr int HN = NT < 2 ? NT : 2, BNH = HN * 32, BNP = BNH + 4;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                         // all waves are done reading the stage buffers
-  constexpr int CTW = (NT == 4 && 64 * 36 > 32 * BNP) ? 64 * 36 : 32 * BNP;   // floats per wave (the V^T pack pass stores its tile transposed)
-  float* ct = reinterpret_cast<float*>(smem) + wave * CTW;
-  constexpr int L4 = BNH / 4, RPP = 64 / L4;
-  const int c4 = lane % L4, rsub = lane / L4;
-  __bf16* out16 = reinterpret_cast<__bf16*>(p.out16);
-#pragma unroll
-  for (int h = 0; h < NT / HN; ++h) {
-    if constexpr (NT == 4) {
-      if (p.pk_q) {   // fused qkv projection: this 32-token x 64-column tile is Q, K or V of one 32-key attention tile
-        // `heads` heads of head_dim D = 8, 16 or 32 (C = heads * D, a multiple of 64); a 64-column pass holds 64/D heads of
-        // NCH 16-deep chunks each (head_dim 8 is zero-padded to one 16-deep chunk: AttnGeom<8>::DP = 16)
-        const int D = p.pk_D, nheads = p.pk_heads, C = nheads * D, NCH = D < 16 ? 1 : D >> 4, HPP = 64 / D, DPq = D < 16 ? 16 : D;
-        const int mrow0 = m0 + wave * 32, nb = n0 + h * BNH;
-        if (mrow0 >= M || nb >= 3 * C) continue;
-        const int b = (int)p.fd_hw.div((unsigned)mrow0), tile = (mrow0 - b * HW) >> 5;
-        const int region = nb / C, head0 = (nb - region * C) / D;      // 0 = Q, 1 = K, 2 = V
-        const int kt_bytes = NCH * 1024, rv = D <= 16 ? D + 1 : 32, tile_bytes = kt_bytes + 4 * rv * 16;
-        if (region < 2) {
-          // Q / K: row-major tile [token][64 + 4], bias (and the softmax scale for Q) folded in on the way
-          const float mulv = region == 0 ? p.pk_qscale : 1.0f;
-#pragma unroll
-          for (int q = 0; q < HN; ++q) {
-            const float bcol = p.bias[nb + q * 32 + lr];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + q * 32 + lr] = (acc[h * HN + q][r] + bcol) * mulv;
-          }
-          // lane (hh = lane >> 5, token = lane & 31) owns components 16c + 8hh .. +7 of chunk c of every head
-          const int tok = lane & 31, hh = lane >> 5;
-          for (int hp = 0; hp < HPP; ++hp) {
-            const size_t bh_tile = (size_t)(b * nheads + head0 + hp) * p.pk_nt + tile;
-            float nk = 0.f;
-            for (int c = 0; c < NCH; ++c) {
-              const float* src = ct + tok * BNP + hp * D + 16 * c + hh * 8;
-              float4 a = make_float4(0.f, 0.f, 0.f, 0.f), e = a;
-              if (16 * c + hh * 8 < D) { a = *reinterpret_cast<const float4*>(src); e = *reinterpret_cast<const float4*>(src + 4); }   // (head_dim 8: the upper half-chunk is padding)
-              bf16x8 v;
-              v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-              v[4] = (__bf16)e.x; v[5] = (__bf16)e.y; v[6] = (__bf16)e.z; v[7] = (__bf16)e.w;
-              if (region == 0) {         // Q[bh][token][DP]
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.pk_q) + (bh_tile * 32 + tok) * DPq + 16 * c + hh * 8) = v;
-              } else {                   // K image: chunk c, lane l = hh*32 + key at byte c*1024 + l*16
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(p.pk_kv) + bh_tile * tile_bytes + c * 1024 + lane * 16) = v;
-              }
-#pragma unroll
-              for (int j2 = 0; j2 < 8; ++j2) { const float f = (float)v[j2]; nk = fmaf(f, f, nk); }   // |q|^2 or |k|^2 of this token
-            }
-            if (region == 1) {           // tile max of |k| on the rounded values (bound of any score of this tile)
-              nk += __shfl_xor(nk, 32);
-#pragma unroll
-              for (int off = 16; off > 0; off >>= 1) nk = fmaxf(nk, __shfl_xor(nk, off));
-              if (lane == 0) p.pk_kmax[bh_tile] = sqrtf(nk) * 1.002f;
-            } else {                     // tile max of |q|^2 (scaled, rounded): attn_pair_bounds_k folds the tiles; NaN -> +inf
-              nk += __shfl_xor(nk, 32);
-              if (!(nk == nk)) nk = INFINITY;
-#pragma unroll
-              for (int off = 16; off > 0; off >>= 1) nk = fmaxf(nk, __shfl_xor(nk, off));
-              if (lane == 0) p.pk_qmax[bh_tile] = nk;
-            }
-          }
-        } else {
-          // V: TRANSPOSED tile [column][32 tokens + 4] so the 4 consecutive keys of a V^T slot group are one float4
-          constexpr int TP = 36;
-#pragma unroll
-          for (int q = 0; q < HN; ++q) {
-            const float bcol = p.bias[nb + q * 32 + lr];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-              *reinterpret_cast<float4*>(ct + (q * 32 + lr) * TP + 8 * g4 + 4 * lh) =
-                  make_float4(acc[h * HN + q][4 * g4] + bcol, acc[h * HN + q][4 * g4 + 1] + bcol,
-                              acc[h * HN + q][4 * g4 + 2] + bcol, acc[h * HN + q][4 * g4 + 3] + bcol);
-          }
-          // V^T image: slab (s, hh), row d, slot j = key (j&3) + 8*(2s + (j>>2)) + 4hh; 64 columns x 4 slabs = 4 items per lane
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int item = it * 64 + lane, col = item & 63, slab = item >> 6;      // col = head-in-pass * D + row
-            const int hp = col / D, row = col - hp * D, sI = slab >> 1, hh = slab & 1;
-            const float* src = ct + col * TP + 16 * sI + 4 * hh;
-            const float4 a = *reinterpret_cast<const float4*>(src), e = *reinterpret_cast<const float4*>(src + 8);
-            bf16x8 v;
-            v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-            v[4] = (__bf16)e.x; v[5] = (__bf16)e.y; v[6] = (__bf16)e.z; v[7] = (__bf16)e.w;
-            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * nheads + head0 + hp) * p.pk_nt + tile) * tile_bytes + kt_bytes;
-            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * rv * 16 + row * 16) = v;
-          }
-          if (D <= 16 && lane < 4 * HPP) {   // the ones row (softmax denominator): row D of each (head, slab) of this pass
-            bf16x8 one;
-#pragma unroll
-            for (int j2 = 0; j2 < 8; ++j2) one[j2] = (__bf16)1.0f;
-            const int hd = head0 + (lane >> 2), slab = lane & 3;
-            unsigned char* vb = reinterpret_cast<unsigned char*>(p.pk_kv) + ((size_t)(b * nheads + hd) * p.pk_nt + tile) * tile_bytes + kt_bytes;
-            *reinterpret_cast<bf16x8*>(vb + (size_t)slab * rv * 16 + D * 16) = one;
-          }
-        }
-        continue;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < HN; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ct[((r & 3) + 8 * (r >> 2) + 4 * lh) * BNP + q * 32 + lr] = acc[h * HN + q][r];
-    const int n = n0 + h * BNH + 4 * c4;
-    if (n >= p.Cout) continue;                          // Cout % 4 == 0: a float4 is all in or all out
-    const bool hi_cols = p.sel_C && n >= p.sel_C;       // sel_C % 64 == 0: a 64-column pass is all low or all high
-    const int no = hi_cols ? n - p.sel_C : n;           // column of mul / res / out
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
-    float gs1 = 0.f, gs2 = 0.f;                         // GroupNorm statistics of this lane's 4 columns over its rows
-#pragma unroll 4
-    for (int pass = 0; pass < 32 / RPP; ++pass) {
-      const int row = pass * RPP + rsub;
-      const int m = m0 + wave * 32 + row;
-      if (m >= M) continue;
-      float4 v = *reinterpret_cast<const float4*>(ct + row * BNP + 4 * c4);
-      int b = 0, y = 0, x = 0;
-      if (need_pos) {
-        b = (int)p.fd_hw.div((unsigned)m);
-        if (p.epi_mask != MASK_NONE || p.sel_C) {       // only the frequency masks need the pixel's position inside its image
-          const int rem = m - b * HW;
-          y = (int)p.fd_w.div((unsigned)rem);
-          x = rem - y * p.W;
-        }
-      }
-      if (p.sel_C && is_low_freq(y, x, p.H, p.W, p.bs, p.low) == hi_cols) continue;   // the other gate owns this pixel
-      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-      if (p.tb) { float4 t = *reinterpret_cast<const float4*>(p.tb + (size_t)b * p.ldtb + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-      if (p.epi_act != ACT_NONE) { v.x = act_apply(v.x, p.epi_act); v.y = act_apply(v.y, p.epi_act); v.z = act_apply(v.z, p.epi_act); v.w = act_apply(v.w, p.epi_act); }
-      if (p.mul) { float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + no); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
-      if (p.rowscale && (!p.sel_C || hi_cols)) { const float rs = p.rowscale[b]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
-      if (p.epi_mask != MASK_NONE) {
-        const bool lowp = is_low_freq(y, x, p.H, p.W, p.bs, p.low);
-        const bool keep = (p.epi_mask == MASK_LOW) ? lowp : !lowp;
-        if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + no); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-      else if (p.res16) {
-        const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.res16) + (size_t)m * p.ldres + no);
-        v.x += (float)t[0]; v.y += (float)t[1]; v.z += (float)t[2]; v.w += (float)t[3];
-      }
-      if (p.gn_sums) {
-        // the sums are those of the values the consumer will normalise: where the result only exists as bf16, of the rounded
-        // values (as head_mix16_k and stream_k do)
-        float4 u = v;
-        if (out16 && !p.out) { u.x = (float)(__bf16)v.x; u.y = (float)(__bf16)v.y; u.z = (float)(__bf16)v.z; u.w = (float)(__bf16)v.w; }
-        gs1 += (u.x + u.y) + (u.z + u.w);
-        gs2 += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
-      }
-      if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + no) = v;
-      if (out16) {
-        bf16x4 o;
-        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(out16 + (size_t)m * p.ldo16 + no) = o;
-      }
-      if (p.out8) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.out8) + (size_t)m * p.ldo8 + no) = pack_e4m3x4(v);
-    }
-    if (p.gn_sums) {
-      // the wave's 32 rows lie in one image (HW % 32 == 0); fold rows (lanes L4 apart), then the lanes of one group.  Every
-      // (32-row wave tile, group) has exactly ONE writer -- a group lies inside one 64-column pass (cpg <= 64) -- which stores
-      // its partial as a double at a slot of its own: no atomics, no clearing pass, and gn_finalize folds the slots of a
-      // (sample, group) in a fixed order, so the statistics are bit-reproducible.
-      const int cpg = p.Cout / p.gn_groups, lg = cpg / 4;             // lanes per group within a row segment
-#pragma unroll
-      for (int off = L4; off < 64; off <<= 1) { gs1 += __shfl_xor(gs1, off); gs2 += __shfl_xor(gs2, off); }
-      const int span = lg < L4 ? lg : L4;
-      for (int off = 1; off < span; off <<= 1) { gs1 += __shfl_xor(gs1, off); gs2 += __shfl_xor(gs2, off); }
-      const int mw = m0 + wave * 32;
-      if (rsub == 0 && (c4 % span) == 0 && mw < M) {
-        const int b = (int)p.fd_hw.div((unsigned)mw), wt = (mw - b * HW) >> 5;
-        double* dst = p.gn_sums + (((size_t)b * (HW >> 5) + wt) * p.gn_groups + n / cpg) * 2;
-        dst[0] = (double)gs1;
-        dst[1] = (double)gs2;
-      }
-    }
-  }
-}
 
 // BK = K elements per stage (64 or 32).  BK = 32 keeps the workgroup at 32 KiB of ring so four of them share one CU:
 // one workgroup's barrier waits, LDS-read latency and epilogue overlap the MFMAs of the others.
@@ -476,7 +255,7 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] *= sc;
   }
-  gemm16_epilogue<NT>(p, acc, smem, m0, n0, M, HW, nsplit, sk);
+  gemm16_epilogue<NT>(p, acc, reinterpret_cast<float*>(smem) + wave * epi_ctw<NT>(), m0 + wave * 32, n0, M, HW, nsplit, sk);
 }
 
 // 3x3 convs with few output channels (Cout <= 64: the full-resolution levels) are bound by the L2 -> LDS stream of their
@@ -694,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p, co
     if (wave_border) taps(st, seg2, std::true_type());
     else taps(st, seg2, std::false_type());
   }
-  gemm16_epilogue<NT>(p, acc, smem, m0, n0, M, HW, nsplit, sk);
+  gemm16_epilogue<NT>(p, acc, reinterpret_cast<float*>(smem) + wave * epi_ctw<NT>(), m0 + wave * 32, n0, M, HW, nsplit, sk);
   if (tile + (int)gridDim.x < gx) __syncthreads();   // the epilogue's wave tiles alias the stage ring the next tile refills
   }
 }
@@ -912,7 +691,7 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(const IGemm p, int nt
     // ---- epilogue of the tile: the shared fused epilogue, once per 32-row block of the wave (it indexes rows as m0 + wave * 32)
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-      gemm16_epilogue<2>(p, acc[rb], epi, m0 + wave * 32 + rb * 32, 0, M, HW, 1, 0);
+      gemm16_epilogue<2>(p, acc[rb], reinterpret_cast<float*>(epi) + wave * epi_ctw<2>(), m0 + wave * 64 + rb * 32, 0, M, HW, 1, 0);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -1141,6 +920,10 @@ __global__ void gn_apply16_k(const float* __restrict__ x, int ldx, int HW, int C
   }
 }
 
+}  // namespace
+void launch_splitk_reduce(const IGemm& p, int nsplit, int64_t M, hipStream_t stream);
+namespace {
+
 template <int NT, int BK, int STAGES, int F8 = 0>
 void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   constexpr int CPR = BK / 8;
@@ -1170,9 +953,7 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   q.nmajor = gx * gy < 256;                             // few M tiles: the weight stream is what to keep inside one L2
   const dim3 grid = q.nmajor ? dim3(gy, gx, nsplit) : dim3(gx, gy, nsplit);
   hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES, F8>), grid, dim3(256), LDS, stream, q);
-  if (nsplit > 1)
-    hipLaunchKernelGGL(splitk_reduce_k, dim3((unsigned)std::min<int64_t>(cdiv64(M * (p.Cout / 4), 256), 2048)), dim3(256), 0, stream,
-                       p, nsplit, M, p.H * p.W);
+  if (nsplit > 1) launch_splitk_reduce(p, nsplit, M, stream);
 }
 
 template <int NT>
@@ -1219,6 +1000,11 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
 
 }  // namespace
 
+void launch_splitk_reduce(const IGemm& p, int nsplit, int64_t M, hipStream_t stream) {
+  hipLaunchKernelGGL(splitk_reduce_k, dim3((unsigned)std::min<int64_t>(cdiv64(M * (p.Cout / 4), 256), 2048)), dim3(256), 0, stream,
+                     p, nsplit, M, p.H * p.W);
+}
+
 bool gemm16_can_fuse_gn(const IGemm& p, int groups) {
   const int64_t M = (int64_t)p.B * p.H * p.W;
   const int NTc = p.Cout <= 32 ? 1 : (p.Cout <= 64 ? 2 : 4);
@@ -1261,7 +1047,7 @@ void launch_gemm16(const IGemm& p, hipStream_t stream) {
   q.fd_w = FastDiv((unsigned)p.W);
   if (q.Cout <= 32) launch_bk<1>(q, M, stream);
   else if (q.Cout <= 64) launch_bk<2>(q, M, stream);
-  else launch_bk<4>(q, M, stream);
+  else if (!launch_gemm256(q, stream)) launch_bk<4>(q, M, stream);   // Cout >= 256 3x3 convs: the eight-wave 256 x 256 tile where it applies
   DDPMIR_HIP_CHECK(hipGetLastError());
 }
 

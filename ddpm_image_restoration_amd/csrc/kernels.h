@@ -66,6 +66,9 @@ struct IGemm {
   // undoes the per-tensor weight scale; out8 / ldo8: optional e4m3 copy of the epilogue result (operand of the next fp8 conv)
   int f8 = 0; float acc_scale = 1.f; void* out8 = nullptr; int ldo8 = 0;
   int nmajor = 0;   // set by the launcher: blockIdx.x is the N tile (weight-bound shapes), see gemm16.hip
+  // gemm256.hip (the 256 x 256 eight-wave tile for 3x3 convs with Cout >= 256): -1 = where it fills the chip (default),
+  // 0 = never (A/B runs, parity tests against the 128-row kernel), 1 = wherever gemm256_supported() allows
+  int tile256 = -1;
   FastDiv fd_hw, fd_w;   // set by launch_gemm16: exact division by H*W and by W (pixel index -> sample, row, column)
   int dbg = 0;   // timing experiments only: 1 skip A loads, 2 skip B loads, 4 skip MFMA, 8 skip stores, 16 skip LDS writes
 };
@@ -74,6 +77,9 @@ void launch_igemm(const IGemm& p, hipStream_t stream);
 void launch_igemm_group(const IGemm* ps, int n, hipStream_t stream);
 bool gemm16_supported(const IGemm& p);
 void launch_gemm16(const IGemm& p, hipStream_t stream);
+bool gemm256_supported(const IGemm& p);                    // gemm256.hip
+bool launch_gemm256(const IGemm& p, hipStream_t stream);   // false: not taken (the caller launches the 128-row kernel)
+long long gemm256_launch_count();                          // launches the tile has taken in this process
 inline size_t gn_sums_doubles(int B, int HW, int groups) { return (size_t)B * (size_t)(HW / 32) * groups * 2; }
 bool gemm16_can_fuse_gn(const IGemm& p, int groups);   // p as it will be launched (without gn_sums)
 // fold the [B][HW/32][G][2] partials written by the epilogue above into per-(b,c) scale / shift of a C-channel tensor.

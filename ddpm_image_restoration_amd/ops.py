@@ -15,6 +15,8 @@ _sigs = {
                                  C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P]),
     "ddpmir_op_set_bf16": (None, [C.c_int]),
     "ddpmir_op_set_gate_select": (None, [C.c_int]),
+    "ddpmir_op_set_tile256": (None, [C.c_int]),
+    "ddpmir_op_gemm256_launches": (C.c_longlong, []),
     "ddpmir_op_conv_time": (C.c_int, [C.c_int] * 11 + [C.POINTER(C.c_float)]),
     "ddpmir_op_gn_scale_shift": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "ddpmir_op_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
@@ -89,6 +91,15 @@ def conv(x, w, bias=None, scale=None, shift=None, pro_act=None, pro_mask=None, b
                             _p(res), int(nchw_out), _p(out))
     _chk(lib, rc, "op_conv")
     return out
+
+
+def set_tile256(mode: int):
+    """IGemm::tile256 for the GEMM ops of this module: -1 auto (default), 0 never, 1 wherever gemm256_supported()."""
+    _lib_ops().ddpmir_op_set_tile256(int(mode))
+
+
+def gemm256_launches() -> int:
+    return int(_lib_ops().ddpmir_op_gemm256_launches())
 
 
 def conv_time(b, h, w, cin, cout, k, bf16=True, gelu_norm=False, residual=False, dbg=0, iters=5):

@@ -163,7 +163,10 @@ const char* ddpmir_version(void);
  * -1 (default): in DDPMIR_FP8 mode only, whose error budget e4m3 dominates; 1: in DDPMIR_BF16 mode too (measured: forward error
  * against the fp32 oracle mean 2.0e-3 instead of 1.7e-3 at 256 x 256; restored PSNR against fp32 mode over 64 images
  * +0.0031 +- 0.0018 dB instead of +0.0034 +- 0.0016, i.e. unchanged; -7 % time at 512 x 512); 0: never.  AVIF and DDPMIR_F32
- * always keep fp32. */
+ * always keep fp32.
+ * "gemm256_tile" (-1 / 0 / 1, bf16 / fp8 modes): the 3x3 convs with >= 256 output channels on the 256 x 256 eight-wave tile
+ * (csrc/gemm256.hip) -- -1 (default): where its tiles (x K splits) fill the chip; 0: never (the 128-row kernel, for A/B runs and
+ * parity tests); 1: wherever the shape is supported. */
 int ddpmir_set_option(ddpmir_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus

@@ -28,6 +28,10 @@ void ddpmir_op_set_bf16(int enable);
  * low-frequency half [0,C) or the high-frequency half [C,2C) is kept (webp_inference.py:241-252 masks), so mul / res /
  * out are [B,H,W,C] and rowscale multiplies the high half only */
 void ddpmir_op_set_gate_select(int C);
+/* IGemm::tile256 of the GEMM ops: -1 = the 256 x 256 eight-wave tile where it fills the chip (default), 0 = never, 1 = wherever supported */
+void ddpmir_op_set_tile256(int mode);
+/* launches that tile has taken in this process (proof for a test that its shape did not fall back to the 128-row kernel) */
+long long ddpmir_op_gemm256_launches(void);
 /* device-resident timing of one conv/linear launch on random data (ms per call); gelu_norm adds the fused
  * GroupNorm+GELU prologue; dbg is a kernel-internal experiment mask (0 in normal use) */
 int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int bf16, int gelu_norm, int residual,
