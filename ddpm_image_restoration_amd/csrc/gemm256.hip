@@ -36,6 +36,8 @@
 // over the drained ring.
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const IGemm p, const in
     constexpr bool isA = KIND & 1;
     const int t = t0 + tl;                               // K tile of the whole contraction (wave-uniform)
     const unsigned ldsb = lds0 + slot * HT_BYTES + wave_s * 1024;
-    if (!F8 && t >= nit_main) {                          // second K segment: the block's 1x1 shortcut (bf16)
+    if (t >= nit_main) {                                 // second K segment: the block's 1x1 shortcut (bf16 in both modes)
       const unsigned c0 = (unsigned)(t - nit_main) * 128u;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -148,11 +150,16 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const IGemm p, const in
   // ---- fragment reads: lane (lr, lh) reads row lr of a 32-row sub-tile; key = (lr >> 1) & 7
   const unsigned char* fa = smem + (wr * 64 + lr) * 128;
   const unsigned char* fb = smem + (wc * 32 + lr) * 128;
-  int coff[4];
+  // (F8: the second K segment stays bf16 -- its tiles use the bf16 chunk order and MFMA; its weights carry the fp8 weights'
+  //  power-of-two scale so that one acc_scale undoes both, as in gemm16_kernel)
+  int coff[4], coff16[F8 ? 4 : 1];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c16 = (((lh ^ (lr >> 1)) & 7) ^ (2 * ks)) << 4;
     coff[ks] = F8 ? ((4 * (ks >> 1) + 2 * lh + (ks & 1)) ^ ((lr >> 1) & 7)) << 4      // a[..][2 k8], a[..][2 k8 + 1] = one 32-byte fragment
-                  : (((lh ^ (lr >> 1)) & 7) ^ (2 * ks)) << 4;
+                  : c16;
+    if constexpr (F8) coff16[ks] = c16;
+  }
 
   bf16x8 a[2][4], b[2][4];
   f32x16 acc[4][2];
@@ -163,15 +170,24 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const IGemm p, const in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto rdA = [&](int slot) {
+  // s2: the tile being read belongs to the second K segment (wave-uniform; only ever true in the F8 kernel, where it selects the bf16 chunk order)
+  auto rdA = [&](int slot, bool s2) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a[mt][ks] = *reinterpret_cast<const bf16x8*>(fa + slot * HT_BYTES + mt * 4096 + coff[ks]);
+      for (int ks = 0; ks < 4; ++ks) {
+        int co = coff[ks];
+        if constexpr (F8) co = s2 ? coff16[ks] : co;
+        a[mt][ks] = *reinterpret_cast<const bf16x8*>(fa + slot * HT_BYTES + mt * 4096 + co);
+      }
   };
-  auto rdB = [&](int slot, bf16x8 (&dst)[4]) {
+  auto rdB = [&](int slot, bf16x8 (&dst)[4], bool s2) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) dst[ks] = *reinterpret_cast<const bf16x8*>(fb + slot * HT_BYTES + coff[ks]);
+    for (int ks = 0; ks < 4; ++ks) {
+      int co = coff[ks];
+      if constexpr (F8) co = s2 ? coff16[ks] : co;
+      dst[ks] = *reinterpret_cast<const bf16x8*>(fb + slot * HT_BYTES + co);
+    }
   };
   auto bar = [&]() {
     asm volatile("" ::: "memory");
@@ -181,14 +197,17 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const IGemm p, const in
   };
 
   // phase Q8 = 4 * (tile parity) + quadrant of the pair of K tiles (2 u, 2 u + 1)
-  auto phase = [&](auto q_c, int u) {
+  // S2 (compile time): the phase's K tile belongs to the second segment (bf16 tiles inside the F8 kernel; always false in the bf16 kernel)
+  auto phase = [&](auto q_c, auto s2_c, int u) {
     constexpr int Q8 = decltype(q_c)::value, PAR = Q8 >> 2, q = Q8 & 3, X = PAR, Y = PAR ^ 1;
+    constexpr bool s2 = decltype(s2_c)::value;
     const int t = 2 * u + PAR, ph = 4 * t + q;
     // ---------------- read section
-    if constexpr (q == 0) rdA(4 * PAR + 1);
-    if constexpr (q == 1) rdB(4 * PAR + 2, b[Y]);
-    if constexpr (q == 2) rdA(4 * PAR + 3);
-    if constexpr (q == 3) { if (t + 1 < KT) rdB(4 * (PAR ^ 1), b[Y]); }
+    const bool s2n = F8 && t0 + t + 1 >= nit_main;      // the NEXT tile's kind only selects the chunk order of its B0 read
+    if constexpr (q == 0) rdA(4 * PAR + 1, s2);
+    if constexpr (q == 1) rdB(4 * PAR + 2, b[Y], s2);
+    if constexpr (q == 2) rdA(4 * PAR + 3, s2);
+    if constexpr (q == 3) { if (t + 1 < KT) rdB(4 * (PAR ^ 1), b[Y], s2n); }
     __builtin_amdgcn_sched_barrier(0);
     if (ph + D < G) issue(std::integral_constant<int, (q + D) & 3>{}, t + (q + D) / 4, (Q8 + D) & 7);
     bar();
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const IGemm p, const in
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_setprio(1);
     constexpr int MI = (q >= 2) ? 2 : 0, NI = (q == 1 || q == 2) ? 1 : 0, BS = (q == 0 || q == 3) ? X : Y;
-    if constexpr (F8) {
+    if constexpr (F8 && !s2) {
       typedef int i32x4 __attribute__((ext_vector_type(4)));
       typedef int i32x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
@@ -231,25 +250,41 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const IGemm p, const in
   issue(std::integral_constant<int, 0>{}, 1, 4);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // half-tiles 0, 1, 2 landed; 3, 4 in flight
   bar();
-  rdB(0, b[0]);
+  rdB(0, b[0], F8 && t0 >= nit_main);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slot 0 is refilled (half-tile 8) before group 1's first multiply section
   if (wr == 1) bar();
-  for (int u = 0; u < (KT >> 1); ++u) {
-    phase(std::integral_constant<int, 0>{}, u);
-    phase(std::integral_constant<int, 1>{}, u);
-    phase(std::integral_constant<int, 2>{}, u);
-    phase(std::integral_constant<int, 3>{}, u);
-    phase(std::integral_constant<int, 4>{}, u);
-    phase(std::integral_constant<int, 5>{}, u);
-    phase(std::integral_constant<int, 6>{}, u);
-    phase(std::integral_constant<int, 7>{}, u);
+  using no_t = std::integral_constant<bool, false>;
+  using yes_t = std::integral_constant<bool, true>;
+  // F8 with a second segment: the main tiles of this launch (host: an even number, one split) run the e4m3 phases, the rest the bf16 ones
+  const int KT1 = (F8 && p.Cinb) ? nit_main : KT;
+  for (int u = 0; u < (KT1 >> 1); ++u) {
+    phase(std::integral_constant<int, 0>{}, no_t{}, u);
+    phase(std::integral_constant<int, 1>{}, no_t{}, u);
+    phase(std::integral_constant<int, 2>{}, no_t{}, u);
+    phase(std::integral_constant<int, 3>{}, no_t{}, u);
+    phase(std::integral_constant<int, 4>{}, no_t{}, u);
+    phase(std::integral_constant<int, 5>{}, no_t{}, u);
+    phase(std::integral_constant<int, 6>{}, no_t{}, u);
+    phase(std::integral_constant<int, 7>{}, no_t{}, u);
   }
-  if (KT & 1) {                                          // odd tile count: the last tile has even parity again
+  if constexpr (F8) {
+    for (int u = (KT1 >> 1); u < (KT >> 1); ++u) {
+      phase(std::integral_constant<int, 0>{}, yes_t{}, u);
+      phase(std::integral_constant<int, 1>{}, yes_t{}, u);
+      phase(std::integral_constant<int, 2>{}, yes_t{}, u);
+      phase(std::integral_constant<int, 3>{}, yes_t{}, u);
+      phase(std::integral_constant<int, 4>{}, yes_t{}, u);
+      phase(std::integral_constant<int, 5>{}, yes_t{}, u);
+      phase(std::integral_constant<int, 6>{}, yes_t{}, u);
+      phase(std::integral_constant<int, 7>{}, yes_t{}, u);
+    }
+  }
+  if ((KT & 1) && KT1 == KT) {                           // odd tile count (never with an F8 second segment): the last tile has even parity again
     const int u = KT >> 1;
-    phase(std::integral_constant<int, 0>{}, u);
-    phase(std::integral_constant<int, 1>{}, u);
-    phase(std::integral_constant<int, 2>{}, u);
-    phase(std::integral_constant<int, 3>{}, u);
+    phase(std::integral_constant<int, 0>{}, no_t{}, u);
+    phase(std::integral_constant<int, 1>{}, no_t{}, u);
+    phase(std::integral_constant<int, 2>{}, no_t{}, u);
+    phase(std::integral_constant<int, 3>{}, no_t{}, u);
   }
   if (wr == 0) bar();
 
@@ -275,24 +310,27 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const IGemm p, const in
 }  // namespace
 
 // Shapes the eight-wave tile takes (everything else stays on gemm16_kernel): 3x3, whole 256-column tiles, whole 128-byte
-// channel chunks, operands addressable with 32-bit offsets; the second K segment only in bf16 mode.
+// channel chunks (of both K segments), operands addressable with 32-bit offsets.
 bool gemm256_supported(const IGemm& p) {
   const int eb = p.f8 ? 1 : 2;
   const int64_t M = (int64_t)p.B * p.H * p.W;
   const size_t lim = (size_t)1 << 31;
-  const int ktall = p.taps * ((p.Cin * eb) >> 7) + ((p.Cinb * 2) >> 7);
+  const int ktall = 9 * ((p.Cin * eb) >> 7) + ((p.Cinb * 2) >> 7);
   return p.taps == 9 && p.Cout >= 256 && (p.Cout % 256) == 0 && ((p.Cin * eb) % 128) == 0 && p.Cin > 0 && M >= 256 && ktall >= 4 &&
-         !p.pk_q && !p.tap_pack && (!p.Cinb || (!p.f8 && (p.Cinb % 64) == 0 && (size_t)M * p.lda16b * 2 < lim && (size_t)p.Cout * p.Cinb * 2 < lim)) &&
+         !p.pk_q && !p.tap_pack && (!p.Cinb || ((p.Cinb % 64) == 0 && p.A16b && p.Wt16b && (size_t)M * p.lda16b * 2 < lim && (size_t)p.Cout * p.Cinb * 2 < lim)) &&
          (size_t)M * p.lda16 * eb + (size_t)(p.W + 1) * p.lda16 * eb < lim && (size_t)p.taps * p.Cout * p.Cin * eb < lim &&
-         (!p.gn_sums || ((p.H * p.W) % 32) == 0);
+         (!p.gn_sums || ((p.H * p.W) % 32) == 0) &&
+         (!(p.f8 && p.Cinb) || ((9 * (p.Cin >> 7)) % 2 == 0 && ((p.Cinb >> 6) % 2) == 0));   // e4m3 + bf16 segment: whole tile pairs of each kind
 }
 
 // split-K factor for `tiles` output tiles and `ktall` K tiles (1 = none): fill the chip, keep >= 4 K tiles per split
-int gemm256_splits(const IGemm& p, int64_t tiles, int ktall, int n_cu) {
+// (measured, tools/gemm256_ab.py: a split that leaves >= 16 K tiles wins 1.08-1.3x over the 128-row kernel, a shorter one loses to
+//  the fp32 round trip of the partial sums; `forced` keeps the old >= 4 so that the tests reach the split path with small shapes)
+int gemm256_splits(const IGemm& p, int64_t tiles, int ktall, int n_cu, bool forced) {
   const int64_t M = (int64_t)p.B * p.H * p.W;
   const bool linear = p.epi_mask == MASK_NONE && (p.out || p.out16 || p.out8) && !p.pk_q && !p.sel_C && !p.gn_sums && p.splitk_ws;
-  if (!linear || tiles >= (3 * n_cu) / 4) return 1;
-  int ns = (int)std::min<int64_t>(cdiv64(n_cu, tiles), ktall / 4);
+  if (!linear || tiles >= (3 * n_cu) / 4 || (!forced && ktall < 64) || (p.f8 && p.Cinb)) return 1;   // (36 K tiles in two splits measured 0.90-0.92x)
+  int ns = (int)std::min<int64_t>(cdiv64(n_cu, tiles), ktall / (forced ? 4 : 16));
   ns = (int)std::min<int64_t>(ns, (int64_t)(p.splitk_ws_bytes / ((size_t)M * p.Cout * sizeof(float))));
   return ns < 1 ? 1 : ns;
 }
@@ -304,8 +342,21 @@ void launch_splitk_reduce(const IGemm& p, int nsplit, int64_t M, hipStream_t str
 static std::atomic<long long> g_launches{0};
 long long gemm256_launch_count() { return g_launches.load(); }
 
+// DDPMIR_GEMM256_LOG=1 (diagnostics, read once): one stderr line per 3x3 launch with Cout >= 256 saying which kernel took it and why
+static bool log_enabled() {
+  static const bool on = [] { const char* e = getenv("DDPMIR_GEMM256_LOG"); return e && *e && *e != '0'; }();
+  return on;
+}
+static bool declined(const IGemm& p, const char* why) {
+  if (log_enabled() && p.taps == 9 && p.Cout >= 256)
+    fprintf(stderr, "[gemm256] B=%d %dx%d %d->%d%s%s%s: 128-row kernel (%s)\n", p.B, p.H, p.W, p.Cin, p.Cout, p.f8 ? " e4m3" : "",
+            p.Cinb ? " +seg2" : "", p.gn_sums ? " +gn" : "", why);
+  return false;
+}
+
 bool launch_gemm256(const IGemm& p, hipStream_t stream) {
-  if (p.tile256 == 0 || !gemm256_supported(p)) return false;
+  if (p.tile256 == 0) return declined(p, "option");
+  if (!gemm256_supported(p)) return declined(p, "unsupported shape");
   const int64_t M = (int64_t)p.B * p.H * p.W;
   static int n_cu = 0;
   static PerDeviceOnce once;
@@ -321,13 +372,13 @@ bool launch_gemm256(const IGemm& p, hipStream_t stream) {
   const int ntn = p.Cout >> 8;
   const int64_t tiles = cdiv64(M, 256) * ntn;
   const int eb = p.f8 ? 1 : 2;
-  const int ktall = p.taps * ((p.Cin * eb) >> 7) + ((p.Cinb * 2) >> 7);
+  const int ktall = 9 * ((p.Cin * eb) >> 7) + ((p.Cinb * 2) >> 7);
   const int cu = n_cu > 0 ? n_cu : 256;
-  const int nsplit = gemm256_splits(p, tiles, ktall, cu);
-  // auto mode: only where the tile fills the chip (with the K split where the epilogue allows one); few-tile launches with a
-  // fused epilogue stay on the 128-row kernel, which has twice the tiles
-  if (p.tile256 < 0 && tiles * nsplit < (3 * cu) / 4) return false;
-  if (ktall / nsplit < 2) return false;
+  const int nsplit = gemm256_splits(p, tiles, ktall, cu, p.tile256 > 0);
+  // auto mode: only where the tile fills the chip (with the K split where the epilogue allows one and the split still leaves
+  // a long K loop); few-tile launches with a fused epilogue stay on the 128-row kernel, which has twice the tiles
+  if (p.tile256 < 0 && tiles * nsplit < (3 * cu) / 4) return declined(p, "too few tiles");
+  if (ktall / nsplit < 2) return declined(p, "K too short");
   IGemm q = p;
   q.nmajor = 0; q.tap_pack = 0;
   const dim3 grid((unsigned)tiles, (unsigned)nsplit, 1);
@@ -335,6 +386,9 @@ bool launch_gemm256(const IGemm& p, hipStream_t stream) {
   else hipLaunchKernelGGL((gemm256_kernel<false>), grid, dim3(512), RING_BYTES, stream, q, ntn);
   if (nsplit > 1) launch_splitk_reduce(p, nsplit, M, stream);
   g_launches.fetch_add(1);
+  if (log_enabled())
+    fprintf(stderr, "[gemm256] B=%d %dx%d %d->%d%s%s%s: 256 tile, %lld tiles x %d splits (%d K tiles)\n", p.B, p.H, p.W, p.Cin, p.Cout,
+            p.f8 ? " e4m3" : "", p.Cinb ? " +seg2" : "", p.gn_sums ? " +gn" : "", (long long)tiles, nsplit, ktall);
   return true;
 }
 

@@ -309,6 +309,42 @@ int ddpmir_op_conv_dual_bf16(const float* x1, int B, int H, int W, int C1, const
   });
 }
 
+int ddpmir_op_conv_dual_fp8(const float* x1, int B, int H, int W, int C1, const float* w1_oihw, const float* x2, int C2,
+                            const float* w2_oi, const float* bias, int Cout, float* out) {
+  return guarded([&] {
+    if ((Cout % 4) || (C1 % 16) || (C2 % 8) || Cout <= 32) throw std::runtime_error("conv_dual_fp8: unsupported shape");
+    Dev d;
+    const size_t M = (size_t)B * H * W;
+    auto bf = [](float f) {
+      unsigned int u;
+      memcpy(&u, &f, 4);
+      return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    };
+    float amax = 0.f;
+    for (size_t i = 0; i < (size_t)Cout * C1 * 9; ++i) amax = std::max(amax, std::fabs(w1_oihw[i]));
+    const int kexp = amax > 0.f ? (int)std::floor(std::log2(448.0 / (double)amax)) : 0;
+    const float sw = std::ldexp(1.0f, kexp);
+    std::vector<unsigned char> w8((size_t)9 * Cout * C1, 0), x8(M * C1, 0);
+    std::vector<unsigned short> wb((size_t)Cout * C2, 0), xb(M * C2, 0);
+    for (int o = 0; o < Cout; ++o) {
+      for (int c = 0; c < C1; ++c)
+        for (int t = 0; t < 9; ++t) w8[((size_t)t * Cout + o) * C1 + c] = f32_to_e4m3(w1_oihw[((size_t)o * C1 + c) * 9 + t] * sw);
+      for (int c = 0; c < C2; ++c) wb[(size_t)o * C2 + c] = bf(w2_oi[(size_t)o * C2 + c] * sw);
+    }
+    for (size_t i = 0; i < M * C1; ++i) x8[i] = f32_to_e4m3(x1[i]);
+    for (size_t i = 0; i < M * C2; ++i) xb[i] = bf(x2[i]);
+    IGemm p;
+    p.B = B; p.H = H; p.W = W; p.Cin = C1; p.Cout = Cout; p.taps = 9; p.bias = d.up(bias, Cout);
+    p.A16 = d.up(x8.data(), x8.size()); p.lda16 = C1; p.Wt16 = d.up(w8.data(), w8.size()); p.f8 = 1; p.acc_scale = std::ldexp(1.0f, -kexp);
+    p.A16b = d.up(xb.data(), xb.size()); p.lda16b = C2; p.Wt16b = d.up(wb.data(), wb.size()); p.Cinb = C2;
+    p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); p.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
+    float* o = d.alloc<float>(M * Cout);
+    p.out = o; p.ldo = Cout;
+    p.tile256 = g_tile256; launch_gemm16(p, nullptr);
+    d.down(out, o, M * Cout);
+  });
+}
+
 int ddpmir_op_qkv_attention_bf16(const float* x, int B, int N, int C, int heads, const float* w_in, const float* b_in,
                                  int fused, float* out) {
   return guarded([&] {

@@ -24,6 +24,7 @@ _sigs = {
     "ddpmir_op_attention_bf16_ex": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
     "ddpmir_op_conv_gnstats_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "ddpmir_op_conv_dual_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "ddpmir_op_conv_dual_fp8": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "ddpmir_op_qkv_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "ddpmir_op_attention_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ddpmir_op_block_transform": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float,
@@ -165,6 +166,17 @@ def conv_dual_bf16(x1, w1, x2, w2, bias):
     out = np.empty((b, h, wd, cout), np.float32)
     _chk(lib, lib.ddpmir_op_conv_dual_bf16(_p(x1), b, h, wd, c1, _p(w1), k, _p(x2), x2.shape[-1], _p(w2), _p(bias), cout,
                                            _p(out)), "op_conv_dual")
+    return out
+
+
+def conv_dual_fp8(x1, w1, x2, w2, bias):
+    """conv3x3(x1, w1) with e4m3 operands + conv1x1(x2, w2) in bf16 + bias in one launch (fp8 mode's conv_out); NHWC in/out."""
+    lib = _lib_ops()
+    x1, w1, x2, w2, bias = _f(x1), _f(w1), _f(x2), _f(w2), _f(bias)
+    b, h, wd, c1 = x1.shape
+    cout = w1.shape[0]
+    out = np.empty((b, h, wd, cout), np.float32)
+    _chk(lib, lib.ddpmir_op_conv_dual_fp8(_p(x1), b, h, wd, c1, _p(w1), _p(x2), x2.shape[-1], _p(w2), _p(bias), cout, _p(out)), "op_conv_dual_fp8")
     return out
 
 

@@ -57,6 +57,10 @@ int ddpmir_op_conv_gnstats_bf16(const float* x, int B, int H, int W, int Cin, co
  * 1x1 shortcut folded in (webp_inference.py:326-327).  x1 [B,H,W,C1], x2 [B,H,W,C2], out [B,H,W,Cout]. */
 int ddpmir_op_conv_dual_bf16(const float* x1, int B, int H, int W, int C1, const float* w1_oihw, int ksize, const float* x2,
                              int C2, const float* w2_oi, const float* bias, int Cout, float* out);
+/* the same in DDPMIR_FP8 arithmetic: the 3x3 segment with OCP e4m3 operands (per-tensor power-of-two weight scale), the 1x1
+ * shortcut segment in bf16 with its weights on the same scale, one acc_scale in the epilogue (Context::conv8 with a shortcut). */
+int ddpmir_op_conv_dual_fp8(const float* x1, int B, int H, int W, int C1, const float* w1_oihw, const float* x2, int C2,
+                            const float* w2_oi, const float* bias, int Cout, float* out);
 /* qkv projection (nn.MultiheadAttention in_proj, webp_inference.py:295) + attention core through the bf16 path:
  * x [B,N,C] -> out [B,N,C] (before out_proj).  fused = 1: the projection's epilogue writes the attention operand
  * images directly (head_dim 16, 4 heads, N % 32 == 0); fused = 0: fp32 qkv tensor + separate packing kernel. */

@@ -83,18 +83,25 @@ def test_conv_bf16_tile256(ops, B, H, W, Cin, Cout):
 
 
 def test_conv_bf16_tile256_auto_mode_takes_chip_filling_shapes_only(ops):
-    """tile256 = -1: B=8, 64 x 64, 64 -> 256 has 128 tiles; with the K split (linear epilogue) they fill the chip and the tile
-    takes the launch; one tile of 16 x 16 pixels stays on the 128-row kernel."""
-    x = rnd(8, 64, 64, 64, seed=4)
+    """tile256 = -1 (measured policy, tools/gemm256_ab.py): 256 whole tiles take the launch unsplit (B=16, 64 x 64, 64 -> 256);
+    64 tiles with a long K loop (B=8, 32 x 32, 512 -> 512: 72 K tiles, four splits of 18) too; 128 tiles with a short K loop
+    (B=8, 64 x 64, 64 -> 256: 9 K tiles) and a single tile stay on the 128-row kernel."""
+    ops.set_tile256(-1)
     w = rnd(256, 64, 3, 3, seed=5, scale=1.0 / 24)
     b = rnd(256, seed=6)
+    x = rnd(16, 64, 64, 64, seed=4)
     n0 = ops.gemm256_launches()
-    ops.set_tile256(-1)
     got = ops.conv(nhwc(x), w, b, bf16="dma")
     assert ops.gemm256_launches() == n0 + 1
-    close(nchw(got), O.conv2d(bf(x), bf(w), b, 1), 3e-5)
+    close(nchw(got)[:2], O.conv2d(bf(x[:2]), bf(w), b, 1), 3e-5)
+    close(nchw(got)[15:], O.conv2d(bf(x[15:]), bf(w), b, 1), 3e-5)
+    ops.conv(nhwc(x[:8]), w, b, bf16="dma")
     ops.conv(nhwc(x[:1, :, :16, :16]), w, b, bf16="dma")
     assert ops.gemm256_launches() == n0 + 1
+    x5, w5, b5 = rnd(8, 512, 32, 32, seed=14), rnd(512, 512, 3, 3, seed=15, scale=1.0 / 68), rnd(512, seed=16)
+    got5 = ops.conv(nhwc(x5), w5, b5, bf16="dma")
+    assert ops.gemm256_launches() == n0 + 2
+    close(nchw(got5)[:1], O.conv2d(bf(x5[:1]), bf(w5), b5, 1), 3e-5)
 
 
 def test_conv_bf16_tile256_deterministic(ops):
@@ -163,6 +170,31 @@ def test_conv_fp8_tile256_is_exact_on_integer_data(ops):
         ref = O.conv2d(x.transpose(0, 3, 1, 2), wt, bias, 1).transpose(0, 2, 3, 1)
         got, old = both(ops, lambda: ops.conv(x, wt, bias, bf16="fp8"))
         assert np.array_equal(got, ref), (b, h, w, cin, cout, float(np.abs(got - ref).max()))
+        assert np.array_equal(old, ref)
+
+
+def test_conv_fp8_second_k_segment_is_exact_on_integer_data(ops):
+    """fp8 mode's conv_out: e4m3 3x3 segment + bf16 1x1 shortcut segment under one accumulator scale, on the 128-row kernel and
+    (shapes with whole tile pairs of each kind) on the eight-wave tile, whose e4m3 phases hand over to bf16 phases mid-stream.
+    Exactly representable data -> equality with the fp32 convolution."""
+    rng = np.random.default_rng(13)
+    for (b, h, w, c1, c2, cout, tile) in ((2, 12, 16, 256, 128, 256, True), (1, 16, 16, 512, 256, 512, True), (3, 16, 16, 256, 1024, 256, True),
+                                          (2, 8, 12, 128, 64, 128, False), (1, 16, 16, 128, 64, 256, False)):
+        x1 = rng.integers(-4, 5, (b, h, w, c1)).astype(np.float32)
+        x2 = rng.integers(-6, 7, (b, h, w, c2)).astype(np.float32)
+        w1 = (rng.integers(-3, 4, (cout, c1, 3, 3)) * 0.125).astype(np.float32)
+        w1[0, 0, 0, 0] = 0.375
+        w2 = (rng.integers(-5, 6, (cout, c2)) * 0.0625).astype(np.float32)
+        bias = rng.integers(-2, 3, cout).astype(np.float32)
+        ref = (O.conv2d(x1.transpose(0, 3, 1, 2), w1, bias, 1) +
+               O.conv2d(x2.transpose(0, 3, 1, 2), w2[:, :, None, None], np.zeros(cout, np.float32), 0)).transpose(0, 2, 3, 1)
+        n0 = ops.gemm256_launches()
+        ops.set_tile256(1)
+        got = ops.conv_dual_fp8(x1, w1, x2, w2, bias)
+        assert (ops.gemm256_launches() > n0) == tile, (c1, c2, cout)
+        ops.set_tile256(0)
+        old = ops.conv_dual_fp8(x1, w1, x2, w2, bias)
+        assert np.array_equal(got, ref), (b, h, w, c1, c2, cout, float(np.abs(got - ref).max()))
         assert np.array_equal(old, ref)
 
 
