@@ -207,6 +207,16 @@ class Context {
   void layout_plan(Arena& a, Plan& p, int B, int H, int W) const;
   void free_plan();
   void order_after_caller();   // stream_ waits for what the caller enqueued on the default stream
+  // ---- two concurrent lanes of the device-codec loop (model.hip: loop_two_lanes)
+  std::unique_ptr<Context> lane_;           // the second lane: a context of its own (stream, workspace) on this context's weight blob
+  bool is_lane_ = false;
+  int lanes_opt_ = -1;                      // option "concurrent_lanes": -1 / 0 off (default), 1 free-running lanes, 2 attention launches take turns
+  hipEvent_t attn_wait_ = nullptr, attn_done_ = nullptr;   // around the next full-resolution attention launch (set by the lane scheduler)
+  hipEvent_t lane_done_[2] = {nullptr, nullptr};           // recorded after down1's / up5's attention of this lane
+  bool use_two_lanes(int B, int H, int W, const ddpmir_loop_opts* opts, bool dev_codec) const;
+  void ensure_lane();
+  void loop_two_lanes(const float* y, float* out, int B, int H, int W, int quality, int steps, double eta, double eta_b,
+                      const ddpmir_loop_opts* opts);
 
   void forward(const float* x, const float* t, const float* cl, float* out, hipStream_t s);
   // forward() in three pieces (model.hip): the full-resolution blocks per row range, the levels below for the whole batch

@@ -72,6 +72,8 @@ Context::~Context() {
   (void)hipSetDevice(cfg.device);
   free_plan();
   if (wblob_ && wblob_owned_) (void)hipFree(wblob_);
+  lane_.reset();
+  for (auto e : lane_done_) if (e) (void)hipEventDestroy(e);
   if (attn_general_taken_) (void)hipFree(attn_general_taken_);
   if (pin_in_) (void)hipHostFree(pin_in_);
   if (pin_out_) (void)hipHostFree(pin_out_);
@@ -563,8 +565,20 @@ void Context::profile_enable(int enable) {
   }
   prof_on_ = enable != 0;
   prof_detail_ = enable;
+  if (lane_) lane_->profile_enable(enable);
 }
 void Context::profile_read(const std::string& cls, double* ms, int64_t* launches, double* flops) {
+  if (lane_) {   // two concurrent lanes: a class is the sum over both lanes' launches
+    double m0 = 0, f0 = 0, m1 = 0, f1 = 0; int64_t n0 = 0, n1 = 0;
+    std::unique_ptr<Context> keep = std::move(lane_);
+    profile_read(cls, &m0, &n0, &f0);
+    lane_ = std::move(keep);
+    lane_->profile_read(cls, &m1, &n1, &f1);
+    if (ms) *ms = m0 + m1;
+    if (launches) *launches = n0 + n1;
+    if (flops) *flops = f0 + f1;
+    return;
+  }
   prof_collect();
   if (cls == "codec_host") {   // host milliseconds inside the codec callback of the sampling loop, and its call count
     if (ms) *ms = codec_host_ms_;
@@ -597,6 +611,12 @@ AttnOpts Context::attn_opts() {
 }
 
 void Context::set_option(const std::string& name, double value) {
+  lane_.reset();   // the second lane's context copies the options when it is created (loop_two_lanes)
+  if (name == "concurrent_lanes") {   // -1 auto, 0 never, 1 whenever the loop allows it (see use_two_lanes)
+    if (value != -1 && value != 0 && value != 1 && value != 2) throw std::invalid_argument("concurrent_lanes must be -1, 0, 1 or 2");
+    lanes_opt_ = (int)value;
+    return;
+  }
   if (name == "attention_no_max_bound") {   // log2 units; < 0: every query block takes the general (running-max) kernel
     if (!(value <= 80.0)) throw std::invalid_argument("attention_no_max_bound must be <= 80 (fp32 range of 2^s sums)");
     attn_nm_bound_ = (float)value;
@@ -858,7 +878,11 @@ void Context::run_block16(const BlockW& bw, ActBuf in, int H, int W, ActBuf dest
     prof_begin(bw.level == 0 ? PROF_ATTN_L0 : PROF_ATTN, 4.0 * nn * nn * C * B, s);
     if (attention_bf16_supported(HW, C, k.heads)) {
       const AttnOpts ao = attn_opts();
+      // two concurrent lanes (loop_two_lanes): the full-resolution attention launches of the two lanes take turns -- each runs
+      // beside the OTHER lane's convolutions / streaming passes / deep levels, never beside the other lane's attention
+      if (bw.level == 0 && attn_wait_) DDPMIR_HIP_CHECK(hipStreamWaitEvent(s, attn_wait_, 0));
       launch_attention_bf16(prepack ? nullptr : p.qkv, p.att, C, B, HW, C, k.heads, p.attn_ws, s, p.att16, &ao);
+      if (bw.level == 0 && attn_done_) DDPMIR_HIP_CHECK(hipEventRecord(attn_done_, s));
     } else {
       launch_attention(p.qkv, p.att, C, B, HW, C, k.heads, s);
       launch_gn_apply16(p.att, C, B, HW, C, nullptr, nullptr, ACT_NONE, p.att16, C, nullptr, 0, s);
@@ -1327,6 +1351,7 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
                                          builtin_host_codec_error() + ")");
   }
   DDPMIR_HIP_CHECK(hipSetDevice(cfg.device));
+  if (use_two_lanes(B, H, W, opts, c.dev_codec)) { loop_two_lanes(y, out, B, H, W, quality, steps, eta, eta_b, opts); return; }
   ensure_plan(B, H, W);
   order_after_caller();   // y (and an injected noise tensor) come from the caller's stream
   Plan& p = plan_;
@@ -1457,6 +1482,108 @@ void Context::ddrm_sample_loop(const float* y, float* out, int B, int H, int W, 
   fb_ = B;
   DDPMIR_HIP_CHECK(hipMemcpyAsync(out, p.s_xt, n * 4, hipMemcpyDeviceToDevice, s));
   DDPMIR_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// ------------------------------------------------------------------------------------------------ two concurrent lanes
+// Option "concurrent_lanes" (off by default), device-codec JPEG loop, bf16 / fp8 mode, attention in every block.  79 % of a
+// timestep is the two full-resolution attention launches, bound by VALU issue (one v_exp_f32 per score) with the matrix pipe a
+// third busy and HBM idle; the rest -- convolutions, streaming passes, ~150 latency-bound launches of the deep levels -- leaves
+// part of the chip idle (0.65 ms per forward in launches of fewer than 256 workgroups, profiles/r03_jpeg_forward_timeline.txt).  The experiment: split the batch into two
+// lanes that run CONCURRENTLY -- this context and a second one that shares its weight blob, each with its own stream and
+// workspace (two workspaces for B / 2 = one for B), both enqueued by one host thread; 1 = free-running, 2 = events make the four
+// full-resolution attention launches of a timestep take turns so that each runs beside the other lane's non-attention work only.
+// Measured (tools/lanes_ab.py, profiles/r04_lanes_ab.txt): free-running x1.005-1.011 on the headline workload, x1.02 at 128 x 128,
+// B = 64; taking turns x0.99 -- a measured "no" for the headline, so the default stays one lane.  Images are independent and the
+// noise is keyed by the global image index: each lane produces exactly what the single-lane loop produces for its half.
+bool Context::use_two_lanes(int B, int H, int W, const ddpmir_loop_opts* opts, bool dev_codec) const {
+  if (is_lane_ || lanes_opt_ == 0 || !dev_codec || !use_gemm16() || cfg.use_graph || opts->noise || opts->trace) return false;
+  if (B < 2 || (B % 2) != 0 || cfg.attn_min_level != 0) return false;
+  // -1 (default) = off: measured on MI355X (profiles/r04_lanes_ab.txt) the lanes buy 0.5-1 % on the headline workload and 2 % at
+  // 128 x 128, B = 64 -- the hardware runs the two streams side by side, but the attention launches already fill every CU
+  return lanes_opt_ >= 1;
+}
+
+void Context::ensure_lane() {
+  if (lane_) return;
+  std::unique_ptr<Context> c(new Context(cfg));
+  c->is_lane_ = true;
+  c->attn_nm_bound_ = attn_nm_bound_; c->fp8_min_ch_ = fp8_min_ch_; c->stream16_opt_ = stream16_opt_; c->tile256_opt_ = tile256_opt_;
+  c->finalize_weights(wblob_, 0);   // adopts the packed blob: same layout, no upload
+  if (prof_on_) c->profile_enable(prof_detail_);
+  lane_ = std::move(c);
+}
+
+void Context::loop_two_lanes(const float* y, float* out, int B, int H, int W, int quality, int steps, double eta, double eta_b,
+                             const ddpmir_loop_opts* opts) {
+  ensure_lane();
+  Context* L[2] = {this, lane_.get()};
+  const int nb = B / 2;
+  const size_t nh = (size_t)nb * 3 * H * W;
+  LoopConsts c;
+  c.dev_codec = true;
+  c.quality = quality;
+  c.eta = (float)eta; c.eta_b = (float)eta_b;
+  c.one_minus_eta_b = (float)(1.0 - eta_b);
+  c.alpha = opts->phase_alpha >= 0.0 ? opts->phase_alpha : k.phase_alpha;
+  const float coeff = opts->noise_coeff >= 0.0 ? (float)opts->noise_coeff : k.noise_coeff;
+  const int phase_q = opts->phase_q >= 0 ? opts->phase_q : k.phase_q;
+  const int every = opts->phase_every > 0 ? opts->phase_every : k.phase_every;
+  const bool do_phase = quality < phase_q;
+  const int i_first = (opts->start_step >= 0 && opts->start_step < steps) ? opts->start_step : steps - 1;
+  const int i_last = opts->num_steps > 0 ? std::max(0, i_first - opts->num_steps + 1) : 0;
+  for (int l = 0; l < 2; ++l) {
+    Context* X = L[l];
+    X->ensure_plan(nb, H, W);
+    X->order_after_caller();
+    for (auto& e : X->lane_done_)
+      if (!e) DDPMIR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    Plan& p = X->plan_;
+    hipStream_t s = X->stream_;
+    DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_y, y + l * nh, nh * 4, hipMemcpyDeviceToDevice, s));
+    DDPMIR_HIP_CHECK(hipMemcpyAsync(p.s_xt, y + l * nh, nh * 4, hipMemcpyDeviceToDevice, s));
+    if (do_phase) X->phase_prepare(p.s_y, nb, H, W, s, 0);
+    launch_step_params_set(p.sp, i_first, steps, coeff, opts->seed, (opts->image_offset + (uint64_t)l * nb) * (uint64_t)(3 * H * W) / 4,
+                           nullptr, (int64_t)nh, s);
+  }
+  auto finish = [&] {
+    for (Context* X : L) { X->attn_wait_ = nullptr; X->attn_done_ = nullptr; X->fb_ = X->plan_.B; }
+  };
+  try {
+    for (int i = i_first; i >= i_last; --i) {
+      const bool with_phase = i > 0 && do_phase && (i % every) == 0;
+      for (int l = 0; l < 2; ++l) {     // down1 of both lanes: lane 0's attention after lane 1's up5 attention of the step before
+        Context* X = L[l];
+        Plan& p = X->plan_;
+        X->attn_wait_ = l == 0 ? (i == i_first ? nullptr : L[1]->lane_done_[1]) : L[0]->lane_done_[0];
+        if (lanes_opt_ != 2) X->attn_wait_ = nullptr;   // 1: free-running lanes (the better of the two); 2: attention launches take turns
+        X->attn_done_ = X->lane_done_[0];
+        launch_fill_t_p(p.s_t, nb, p.sp, X->stream_);
+        X->fwd_head(p.s_xt, p.s_t, p.s_t, 0, nb, false, X->stream_);
+      }
+      for (int l = 0; l < 2; ++l) {     // the levels below, up5 + head, codec, update
+        Context* X = L[l];
+        Plan& p = X->plan_;
+        hipStream_t s = X->stream_;
+        X->attn_wait_ = l == 0 ? L[1]->lane_done_[0] : L[0]->lane_done_[1];
+        if (lanes_opt_ != 2) X->attn_wait_ = nullptr;
+        X->attn_done_ = X->lane_done_[1];
+        X->fwd_mid(nb, false, s);
+        X->fwd_tail(p.s_theta, 0, nb, false, s);
+        launch_quantize_u8(p.s_theta, p.s_u8, (int64_t)nh, s);
+        launch_jpeg_roundtrip(p.s_u8, p.s_dec, p.s_jpeg, nb, H, W, quality, s);
+        X->step_back(0, nb, with_phase, c, s);
+      }
+    }
+  } catch (...) {
+    finish();
+    for (Context* X : L) (void)hipStreamSynchronize(X->stream_);
+    throw;
+  }
+  finish();
+  for (int l = 0; l < 2; ++l) {
+    DDPMIR_HIP_CHECK(hipMemcpyAsync(out + l * nh, L[l]->plan_.s_xt, nh * 4, hipMemcpyDeviceToDevice, L[l]->stream_));
+    DDPMIR_HIP_CHECK(hipStreamSynchronize(L[l]->stream_));
+  }
 }
 
 void Context::drop_loop_graphs() {

@@ -166,7 +166,11 @@ const char* ddpmir_version(void);
  * always keep fp32.
  * "gemm256_tile" (-1 / 0 / 1, bf16 / fp8 modes): the 3x3 convs with >= 256 output channels on the 256 x 256 eight-wave tile
  * (csrc/gemm256.hip) -- -1 (default): where its tiles (x K splits) fill the chip; 0: never (the 128-row kernel, for A/B runs and
- * parity tests); 1: wherever the shape is supported. */
+ * parity tests); 1: wherever the shape is supported.
+ * "concurrent_lanes" (-1 / 0 off, default; 1; 2): the device-codec JPEG loop in bf16 / fp8 mode splits the batch into two lanes
+ * that run concurrently on two streams (a second context on the same weight blob); 2 additionally makes the full-resolution
+ * attention launches of the lanes take turns.  Each lane's result equals the single-lane loop's on its half of the batch.  An
+ * experiment that measured +0.5-1 % on 256 x 256, B = 16 (+2 % at 128 x 128, B = 64): off by default. */
 int ddpmir_set_option(ddpmir_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus

@@ -796,3 +796,54 @@ def test_two_lane_loop_shares_the_levels_below_full_resolution(name, arch, model
     # bf16 mode: same images through another grouping stay within the loop's bf16 scatter (GEMM tilings differ with the batch)
     g16 = torch.cat([s16.sample(y[a:b], 10, image_offset=a, **kw) for a, b in ((0, 4), (4, 6))])
     assert float((f16 - g16).abs().mean()) < 5e-2
+
+
+@pytest.mark.parametrize("dtype,size,batch,steps,q,mode", [("bf16", 64, 6, 7, 10, 1), ("fp8", 64, 4, 6, 30, 2), ("bf16", 128, 4, 6, 10, 2)])
+def test_two_concurrent_lanes_equal_the_lanes_run_one_after_the_other(dtype, size, batch, steps, q, mode, synth_state):
+    """Option concurrent_lanes (device-codec JPEG loop, bf16 / fp8 mode): the batch is split into two lanes that run concurrently
+    on two streams -- this context and a second one on the same weight blob -- with their full-resolution attention launches
+    taking turns.  Each lane must produce EXACTLY what the single-lane loop produces for that half of the batch on its own
+    (same launch batch -> same kernel selection; the noise is keyed by the global image index), including the FFT phase fix
+    (q 10, every 5th index), slices of the schedule (start_step / num_steps) and repeated calls; profiling counters add up over
+    both lanes."""
+    import torch
+    from ddpm_image_restoration_amd import harness
+    from ddpm_image_restoration_amd.model import JPEGDiffusionModel
+    from ddpm_image_restoration_amd.sampler import DDRMJPEGSampler
+    dev = torch.device("cuda", 0)
+    sd = synth_state(spec.ARCH_JPEG)
+    m = JPEGDiffusionModel(device=dev, dtype=dtype)
+    m.load_state_dict(sd)
+    s = DDRMJPEGSampler(m)
+    x0 = synth.synth_images(batch, size, seed=91)
+    y = harness.COMPRESS[spec.ARCH_JPEG](torch.from_numpy(x0), q).cuda()
+    h = batch // 2
+    m.set_option("concurrent_lanes", 0)
+    halves = torch.cat([s.sample(y[:h], q, steps=steps, seed=5, image_offset=40),
+                        s.sample(y[h:], q, steps=steps, seed=5, image_offset=40 + h)])
+    whole = s.sample(y, q, steps=steps, seed=5, image_offset=40)
+    m.set_option("concurrent_lanes", mode)
+    m.profile(True)
+    lanes = s.sample(y, q, steps=steps, seed=5, image_offset=40)
+    m.profile(False)
+    assert torch.isfinite(lanes).all()
+    assert torch.equal(lanes, halves), float((lanes - halves).abs().max())
+    a_ms, a_n, a_fl = m.profile_read("attention_l0")
+    f_ms, f_n, _ = m.profile_read("forward")
+    assert a_n == 4 * steps and f_n == 2 * steps and a_ms > 0                       # two launches per lane and step; one forward per lane and step
+    assert abs(a_fl - 4 * steps * 4.0 * (size * size) ** 2 * 64 * h) < 1e-6 * a_fl
+    assert torch.equal(s.sample(y, q, steps=steps, seed=5, image_offset=40), lanes)  # again: same bits
+    # (the unsplit batch is a different launch batch: other kernel choices, and the codec's quantisation amplifies the mode's noise floor
+    #  from step to step -- the same restoration, not the same bits)
+    assert float((lanes - whole).abs().mean()) < 0.2
+    # a slice of the schedule, then the rest: the lanes continue from x_t like the single-lane loop
+    a = s.sample(y, q, steps=steps, seed=5, start_step=steps - 1, num_steps=3)
+    m.set_option("concurrent_lanes", 0)
+    b = torch.cat([s.sample(y[:h], q, steps=steps, seed=5, start_step=steps - 1, num_steps=3),
+                   s.sample(y[h:], q, steps=steps, seed=5, start_step=steps - 1, num_steps=3, image_offset=h)])
+    assert torch.equal(a, b)
+    # odd batches and injected noise stay on the single-lane loop (and still work with the option on)
+    m.set_option("concurrent_lanes", 1)
+    odd = s.sample(y[:3], q, steps=3, seed=1)
+    m.set_option("concurrent_lanes", 0)
+    assert torch.equal(odd, s.sample(y[:3], q, steps=3, seed=1))
