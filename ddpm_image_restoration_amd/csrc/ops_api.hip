@@ -442,6 +442,42 @@ int ddpmir_op_attention_bf16_ex(const float* qkv, int B, int N, int C, int heads
   });
 }
 
+// Shader clock under load: one wave on a stream of its own reads s_memtime (shader cycles) against s_memrealtime (100 MHz) for a
+// fixed wall time while the caller runs whatever it wants to characterise on other streams (tools/clock_under_load.py).
+__global__ void clock_sampler_k(unsigned long long* out, unsigned long long wall_ticks) {
+  const unsigned long long w0 = wall_clock64(), c0 = __builtin_readcyclecounter();
+  unsigned long long w = w0;
+  while (w - w0 < wall_ticks) {                // bounded by the wall clock: the wave always exits
+    __builtin_amdgcn_s_sleep(64);
+    w = wall_clock64();
+  }
+  out[0] = __builtin_readcyclecounter() - c0;
+  out[1] = w - w0;
+}
+static hipStream_t g_clk_stream = nullptr;
+static unsigned long long* g_clk_buf = nullptr;
+int ddpmir_op_clock_sample_begin(double ms) {
+  return guarded([&] {
+    if (ms <= 0 || ms > 5000) throw std::runtime_error("clock sample: 0 < ms <= 5000");
+    if (!g_clk_stream) {
+      DDPMIR_HIP_CHECK(hipStreamCreateWithFlags(&g_clk_stream, hipStreamNonBlocking));
+      DDPMIR_HIP_CHECK(hipMalloc(&g_clk_buf, 16));
+    }
+    hipLaunchKernelGGL(clock_sampler_k, dim3(1), dim3(64), 0, g_clk_stream, g_clk_buf, (unsigned long long)(ms * 1e5));
+    DDPMIR_HIP_CHECK(hipGetLastError());
+  });
+}
+int ddpmir_op_clock_sample_end(double* ghz, double* ms) {
+  return guarded([&] {
+    if (!g_clk_stream) throw std::runtime_error("clock sample: begin was not called");
+    DDPMIR_HIP_CHECK(hipStreamSynchronize(g_clk_stream));
+    unsigned long long h[2];
+    DDPMIR_HIP_CHECK(hipMemcpy(h, g_clk_buf, 16, hipMemcpyDeviceToHost));
+    if (ghz) *ghz = (double)h[0] / ((double)h[1] * 10.0);
+    if (ms) *ms = (double)h[1] * 1e-5;
+  });
+}
+
 int ddpmir_op_attention_time(int B, int N, int C, int heads, int mode, int iters, float* ms_per_call) {
   return guarded([&] {
     Dev d;

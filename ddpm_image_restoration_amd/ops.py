@@ -15,6 +15,8 @@ _sigs = {
                                  C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P]),
     "ddpmir_op_set_bf16": (None, [C.c_int]),
     "ddpmir_op_set_gate_select": (None, [C.c_int]),
+    "ddpmir_op_clock_sample_begin": (C.c_int, [C.c_double]),
+    "ddpmir_op_clock_sample_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ddpmir_op_set_tile256": (None, [C.c_int]),
     "ddpmir_op_gemm256_launches": (C.c_longlong, []),
     "ddpmir_op_conv_time": (C.c_int, [C.c_int] * 11 + [C.POINTER(C.c_float)]),
@@ -92,6 +94,20 @@ def conv(x, w, bias=None, scale=None, shift=None, pro_act=None, pro_mask=None, b
                             _p(res), int(nchw_out), _p(out))
     _chk(lib, rc, "op_conv")
     return out
+
+
+def clock_sample_begin(ms: float):
+    """start the one-wave shader-clock sampler (own stream) for `ms` of wall time"""
+    lib = _lib_ops()
+    _chk(lib, lib.ddpmir_op_clock_sample_begin(float(ms)), "clock_sample_begin")
+
+
+def clock_sample_end():
+    """-> (effective shader clock in GHz, sampled wall time in ms)"""
+    lib = _lib_ops()
+    g, m = C.c_double(0), C.c_double(0)
+    _chk(lib, lib.ddpmir_op_clock_sample_end(C.byref(g), C.byref(m)), "clock_sample_end")
+    return g.value, m.value
 
 
 def set_tile256(mode: int):

@@ -66,6 +66,10 @@ int ddpmir_op_conv_dual_fp8(const float* x1, int B, int H, int W, int C1, const 
  * images directly (head_dim 16, 4 heads, N % 32 == 0); fused = 0: fp32 qkv tensor + separate packing kernel. */
 int ddpmir_op_qkv_attention_bf16(const float* x, int B, int N, int C, int heads, const float* w_in, const float* b_in,
                                  int fused, float* out);
+/* shader clock under load: a one-wave kernel on its own stream compares s_memtime with s_memrealtime for `ms` of wall time while
+ * the caller keeps the device busy from other streams; _end waits for it and returns the effective clock in GHz */
+int ddpmir_op_clock_sample_begin(double ms);
+int ddpmir_op_clock_sample_end(double* ghz, double* ms);
 /* device-resident timing of the attention kernels on random data: mode 0 = fp32, 1 = bf16; average ms per call */
 int ddpmir_op_attention_time(int B, int N, int C, int heads, int mode, int iters, float* ms_per_call);
 
