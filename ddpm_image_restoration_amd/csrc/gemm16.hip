@@ -977,7 +977,7 @@ void launch_bk(const IGemm& p, int64_t M, hipStream_t stream) {
   }
   if constexpr (NT <= 2) {
     // full-resolution 3x3 convs with <= 64 output channels: one strip of pixel rows per kernel row serves its three taps
-    if (p.taps == 9 && tiles >= 256 && p.Cin >= 32 && !(p.taps == 9 && p.Cin == 8) && !p.pk_q && !exp_switch("DDPMIR_NO_STRIP") && !GEMM_DBG(p)) {
+    if (p.taps == 9 && tiles >= 256 && p.Cin >= 32 && !(p.taps == 9 && p.Cin == 8) && !p.pk_q && !exp_switch("DDPMIR_NO_STRIP") && !(GEMM_DBG(p) & ~8)) {
 #ifdef DDPMIR_EXPERIMENTS
       if constexpr (NT == 2) {
         if (conv64_ws_supported(p)) { launch_conv64_ws(p, M, stream); return; }   // (experiment: persistent, weights resident in LDS)

@@ -216,7 +216,8 @@ int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int b
     if (gelu_norm) { p.scale = d.up(ones.data(), ones.size()); p.shift = d.up(zeros.data(), zeros.size()); p.pro_act = ACT_GELU; }
     float* o = d.alloc<float>(M * Cout);
     if (residual) { p.res = o; p.ldres = Cout; }
-    p.out = o; p.ldo = Cout; p.dbg = dbg;
+    p.out = o; p.ldo = Cout; p.dbg = dbg & 127;
+    if ((dbg & 128) && (p.out16 || p.out8)) { p.out = nullptr; p.res = nullptr; }   // bit 7: the bf16 / e4m3 copy is the only output (conv1 / conv2 of a block)
     hipEvent_t a, b;
     DDPMIR_HIP_CHECK(hipEventCreate(&a));
     DDPMIR_HIP_CHECK(hipEventCreate(&b));

@@ -68,3 +68,42 @@ def test_groundwork_kernels_compile_without_scratch(src, flags, tmp_path):
         # 24 phases + prologue with the schedule's constants, one final drain, nothing inserted by the compiler
         assert sorted(set(waits)) == ["0", "10", "8"] and waits.count("0") == 1 and waits.count("8") == 13 and waits.count("10") == 12, waits
         assert body.count("s_barrier") == 52 and body.count("v_mfma_f32_32x32x16_bf16") == 192
+
+
+def test_library_gemm256_schedule_and_isa(tmp_path):
+    """csrc/gemm256.hip (the product's eight-wave tile) runs the D = 5 schedule of gemm256_stagger.hip: the barrier-interval model
+    is clean for every K-tile count the launcher can produce (even, odd, the two-tile minimum of a split), and the gfx950 build
+    has no scratch in either instantiation (a scratch reload is a VMEM operation: it would corrupt the counted vmcnt waits),
+    only the schedule's wait constants, and descriptor-addressed LDS-DMA for every operand load."""
+    sys.path.insert(0, MICRO)
+    try:
+        import schedule_check as S
+    finally:
+        sys.path.pop(0)
+    for kt in (2, 3, 4, 5, 9, 18, 19, 27, 36, 38, 72, 76, 152):
+        assert S.gemm256(kt, 5).check() == [], kt
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "g.s"
+    src = os.path.join(ROOT, "ddpm_image_restoration_amd", "csrc", "gemm256.hip")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form", "--cuda-device-only",
+                        "-S", src, "-o", str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    names = re.findall(r"^(_ZN6ddpmir\S*gemm256_kernelILb[01]E\S*):", asm, flags=re.M)
+    assert len(names) == 2, names
+    for nm in names:
+        body = asm[asm.index(nm + ":"):]
+        body = body[:body.index("s_endpgm")]
+        meta = asm[asm.index(".name:           " + nm):]
+        meta = meta[:meta.index(".wavefront_size")] if ".wavefront_size" in meta else meta[:3000]
+        assert re.search(r"\.private_segment_fixed_size:\s+0\b", meta) and re.search(r"\.vgpr_spill_count:\s+0\b", meta), nm
+        assert "scratch_" not in body and "buffer_load_dwordx4" in body and "global_load_lds" not in body
+        # counted waits of the K loop: vmcnt(4) steady state, vmcnt(2) / vmcnt(0) in the tail; never anything else between barriers
+        loop = body[:body.rindex("s_barrier")]
+        assert set(re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)) <= {"0", "2", "4"}, set(re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop))
+        assert loop.count("s_waitcnt vmcnt(4)") >= 9      # prologue + the eight phases of the unrolled pair of K tiles
+        # bf16 kernel: 8 + 4 phases x 8 MFMAs; e4m3 kernel: 8 + 4 e4m3 phases x 4 MFMAs (64-deep) + 8 bf16 phases of the second segment
+        if "ILb1E" in nm: assert body.count("32x32x64_f8f6f4") == 48 and body.count("v_mfma_f32_32x32x16_bf16") == 64
+        else: assert body.count("v_mfma_f32_32x32x16_bf16") == 96
