@@ -14,6 +14,15 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     } else if (MODE == 1) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("v_exp_f16 %0, %0" : "+v"(v[i]));
+    } else if (MODE == 4) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_exp_legacy_f32 %0, %0" : "+v"(v[i]));
+    } else if (MODE == 5) {   // reference points: a plain full-rate VALU op and a cvt
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32 %0, 0x3f7fbe77, %0" : "+v"(v[i]));
+    } else if (MODE == 6) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(v[i]) : "v"(v[i + 1]));
     } else if (MODE == 2) {   // f16 path: cvt_pkrtz (1 per 2) + exp_f16 low + exp_f16 high (SDWA) per pair
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
@@ -53,11 +62,14 @@ void run(const char* name, int wgs_per_cu) {
 }
 
 int main() {
-  for (int w = 1; w <= 2; ++w) {
+  for (int w = 1; w <= 3; ++w) {
     run<0>("v_exp_f32", w);
     run<1>("v_exp_f16", w);
     run<2>("cvt_pkrtz + 2x v_exp_f16_sdwa per pair", w);
     run<3>("2x v_exp_f32 + cvt_pk_bf16 per pair (today)", w);
+    run<4>("v_exp_legacy_f32", w);
+    run<5>("v_mul_f32 (full-rate reference)", w);
+    run<6>("v_cvt_pk_bf16_f32 (8 per 16 elements)", w);
   }
   return 0;
 }

@@ -1,6 +1,6 @@
 """Per-kernel HBM-side traffic of the bench workload from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
 usage: pmc_summary.py <fetch_dir> <write_dir> <n_forwards> [--json FILE --key WORKLOAD_KEY --command "bench command" --class gemm]
-(--class gemm: the roofline "kernel" is the GEMM class -- every gemm16_kernel / conv3x3_strip_kernel / splitk_reduce_k launch of
+(--class gemm: the roofline "kernel" is the GEMM class -- every gemm16_kernel / gemm256_kernel / conv3x3_strip_kernel / splitk_reduce_k launch of
 one forward -- as bench.py reports for the workloads with attention at the bottleneck only)
 FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B); both counters are in KiB.  Durations are the dispatch
 timestamps of the same (profiled) runs.  With --json the bytes per launch of the roofline kernel (the level-0 attention
@@ -71,7 +71,7 @@ if "--json" in sys.argv:
     key = sys.argv[sys.argv.index("--key") + 1]
     cmd = sys.argv[sys.argv.index("--command") + 1] if "--command" in sys.argv else None
     if "--class" in sys.argv and sys.argv[sys.argv.index("--class") + 1] == "gemm":
-        sel = [k for k in fe if ("gemm16_kernel" in k or "conv3x3_strip" in k or "splitk_reduce" in k)]
+        sel = [k for k in fe if ("gemm16_kernel" in k or "gemm256_kernel" in k or "conv3x3_strip" in k or "splitk_reduce" in k)]
         f_kib = sum(fe[k][1] for k in sel) / n
         w_kib = sum(wr.get(k, [0, 0.0, 0.0])[1] for k in sel) / n
         name, nl = "GEMM class: " + ", ".join(sorted(set(k.split("<")[0] for k in sel))), int(sum(fe[k][0] for k in sel) / n)

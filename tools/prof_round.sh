@@ -9,7 +9,7 @@
 #   <tag>_hbm_traffic.txt            per-kernel HBM bytes from two PMC passes (FETCH_SIZE x2, WRITE_SIZE)
 #   ${ROUND}_traffic.json            bytes per launch of the roofline kernel -> bench.py's roofline.traffic (with the source hash)
 tag=$1; key=$2; shift 2
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
