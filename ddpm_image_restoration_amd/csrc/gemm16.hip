@@ -255,6 +255,9 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] *= sc;
   }
+  if constexpr (NT <= 2) {
+    if (p.epi_direct) { gemm16_epilogue_direct_any<NT>(p, acc, m0 + wave * 32, n0, M, HW); return; }
+  }
   gemm16_epilogue<NT>(p, acc, reinterpret_cast<float*>(smem) + wave * epi_ctw<NT>(), m0 + wave * 32, n0, M, HW, nsplit, sk);
 }
 
@@ -276,8 +279,10 @@ __global__ __launch_bounds__(256, (NT == 4 && BK == 32 && F8 == 0) ? 4 : 1) void
 // Needs Cin % 32 == 0 (no channel tail inside a stage) and operands below 2 GiB.
 constexpr unsigned BUF_OOB = 0x80000000u;     // voffset of a lane that must read zeros (+ soffset < 2^31 never wraps)
 
+// (three workgroups per CU = three waves per SIMD: the register allocation is capped at 168 VGPRs so that the LDS footprint, not
+//  an epilogue's address arithmetic, decides the occupancy)
 template <int NT, bool BUF = false>
-__global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p, const int gx) {
+__global__ __launch_bounds__(256, 3) void conv3x3_strip_kernel(const IGemm p, const int gx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BK = 32, ROWB = 64, CPR = 4, RSH = 2, KS = 2, STAGES = 2;
   constexpr int AR = BUF ? BM + 16 : BM + 8;            // strip rows allocated (130 used): row r = pixel m0 - 1 + r
@@ -473,8 +478,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const IGemm p, co
     if (wave_border) taps(st, seg2, std::true_type());
     else taps(st, seg2, std::false_type());
   }
+  if (p.epi_direct) {
+    gemm16_epilogue_direct_any<NT>(p, acc, m0 + wave * 32, n0, M, HW);
+    if (tile + (int)gridDim.x < gx) __builtin_amdgcn_s_barrier();   // every wave is past its last fragment read before the next tile's first DMA lands
+  } else {
   gemm16_epilogue<NT>(p, acc, reinterpret_cast<float*>(smem) + wave * epi_ctw<NT>(), m0 + wave * 32, n0, M, HW, nsplit, sk);
   if (tile + (int)gridDim.x < gx) __syncthreads();   // the epilogue's wave tiles alias the stage ring the next tile refills
+  }
   }
 }
 
@@ -744,6 +754,7 @@ void launch_strip(const IGemm& p, int64_t M, hipStream_t stream) {
   const int gx = (int)cdiv64(M, BM), gy = cdiv(p.Cout, NT * 32);
   IGemm q = p;
   q.nmajor = 0; q.tap_pack = 0;
+  q.epi_direct = p.epi_direct_opt ? epilogue_direct_mode(p, NT * 32) : 0;   // (the strip kernel never splits K)
   // descriptor-addressed loads: whole 32-channel stages and operands below 2 GiB (32-bit offsets with headroom for soffset)
   const size_t lim = size_t(1) << 31;
   const bool buf = (p.Cin % 32) == 0 && (size_t)M * p.lda16 * 2 < lim && (size_t)9 * p.Cout * p.Cin * 2 < lim &&
@@ -950,6 +961,7 @@ void launch_nt(const IGemm& p, int64_t M, hipStream_t stream) {
   }
   IGemm q = p;
   q.tap_pack = tap_pack;
+  q.epi_direct = (NT <= 2 && nsplit == 1 && p.epi_direct_opt) ? epilogue_direct_mode(p, NT * 32) : 0;
   q.nmajor = gx * gy < 256;                             // few M tiles: the weight stream is what to keep inside one L2
   const dim3 grid = q.nmajor ? dim3(gy, gx, nsplit) : dim3(gx, gy, nsplit);
   hipLaunchKernelGGL((gemm16_kernel<NT, BK, STAGES, F8>), grid, dim3(256), LDS, stream, q);

@@ -236,5 +236,96 @@ __device__ __forceinline__ void gemm16_epilogue(const IGemm& p, f32x16 (&acc)[NT
   }
 }
 
+
+// Register-direct epilogue of the 64-column kernels for the plain option sets the full-resolution blocks use (conv1: bias +
+// time bias -> bf16 + GroupNorm partials; conv2: bias -> bf16 (+ fp32); conv_out: bias -> fp32 (+ partials)).  The accumulators
+// go to memory in their own layout -- lane = output column, register = row -- with 4-byte (fp32) / 2-byte (bf16) stores: 32
+// consecutive columns of a row are one 128- / 64-byte piece and the wave's following stores complete the lines in L2
+// (tools/micro/store_pattern.hip: 6.7 TB/s, the same as whole 128-byte rows).  No LDS tile, no barrier, and -- unlike the first
+// attempt of round 4, which kept every option of gemm16_epilogue behind per-element branches and ran 100-150 us slower per
+// launch (profiles/r04_epilogue_direct_ab.txt) -- no branch inside the row loop: the option set is a template argument, whole
+// 32-row wave tiles only (HW % 32 == 0), whole column tiles only.  Same arithmetic in the same order as gemm16_epilogue, so the
+// stored values are bit-identical; the fused statistics differ in summation order only.
+// mode bits: 1 = fp32 output, 2 = bf16 output, 4 = GroupNorm partials.  0 = not eligible (LDS epilogue).
+inline int epilogue_direct_mode(const IGemm& p, int nt_cols) {
+  if (p.pk_q || p.sel_C || p.epi_mask != MASK_NONE || p.out8 || p.mul || p.rowscale || p.res || p.res16 || p.epi_act != ACT_NONE ||
+      p.store != STORE_NHWC || !p.bias || (!p.out && !p.out16) || ((p.H * p.W) & 31) != 0 || (p.Cout % nt_cols) != 0)
+    return 0;
+  if (p.gn_sums) {
+    const int cpg = p.gn_groups > 0 ? p.Cout / p.gn_groups : 0;
+    if (cpg < 4 || (cpg & (cpg - 1)) != 0 || cpg > 64 || (cpg == 64 && nt_cols < 64)) return 0;
+  }
+  // (measured, tools/epilogue_ab.py: with BOTH copies to store the direct form wins for the 3x3 convs -- 8 -> 64: 238 -> 169 us,
+  //  64 -> 64: 359 -> 334 -- and loses for 1x1 launches -- 64 -> 64 at 512 x 512: 182 -> 232 us: those keep the LDS epilogue)
+  if (p.out && p.out16 && p.taps != 9) return 0;
+  return (p.out ? 1 : 0) | (p.out16 ? 2 : 0) | (p.gn_sums ? 4 : 0);
+}
+
+template <int NT, bool OUT32, bool OUT16, bool GN>
+__device__ __forceinline__ void gemm16_epilogue_direct(const IGemm& p, f32x16 (&acc)[NT], int mw0, int n0, int M, int HW) {
+  if (mw0 >= M) return;                                   // (M % 32 == 0: a wave tile is all rows or none)
+  const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+  const int b = (p.tb || GN) ? (int)p.fd_hw.div((unsigned)mw0) : 0;
+  float gs1[NT], gs2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + nt * 32 + lr;
+    const float bias = p.bias[n];
+    const float tbv = p.tb ? p.tb[(size_t)b * p.ldtb + n] : 0.f;
+    float* o32 = OUT32 ? p.out + (size_t)(mw0 + 4 * lh) * p.ldo + n : nullptr;
+    __bf16* o16 = OUT16 ? reinterpret_cast<__bf16*>(p.out16) + (size_t)(mw0 + 4 * lh) * p.ldo16 + n : nullptr;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = (r & 3) + 8 * (r >> 2);               // row of the half-wave's 16: compile-time constant
+      float v = acc[nt][r] + bias;
+      if (p.tb) v += tbv;                                 // (wave-uniform; same order as gemm16_epilogue: (acc + bias) + tb)
+      if (OUT32) o32[(size_t)k * p.ldo] = v;
+      if (OUT16) o16[(size_t)k * p.ldo16] = (__bf16)v;
+      if (GN) {
+        const float u = (OUT16 && !OUT32) ? (float)(__bf16)v : v;   // statistics of what the consumer will read
+        s1 += u;
+        s2 += u * u;
+      }
+    }
+    gs1[nt] = s1; gs2[nt] = s2;
+  }
+  if (GN) {
+    // one writer per (32-row wave tile, group): fold the two row halves (lanes 32 apart), then the lanes of a group
+    const int cpg = p.Cout / p.gn_groups, wt = (mw0 - b * HW) >> 5;
+    if (NT >= 2 && cpg == 64) {
+#pragma unroll
+      for (int nt = 0; nt + 1 < NT; nt += 2) { gs1[nt] += gs1[nt + 1]; gs2[nt] += gs2[nt + 1]; }
+    }
+    const int span = cpg < 32 ? cpg : 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (NT >= 2 && cpg == 64 && (nt & 1)) continue;
+      float s1 = gs1[nt], s2 = gs2[nt];
+      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      for (int off = 1; off < span; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+      const int n = n0 + nt * 32 + lr;
+      if (lh == 0 && (lr & (span - 1)) == 0) {
+        double* dst = p.gn_sums + (((size_t)b * (HW >> 5) + wt) * p.gn_groups + n / cpg) * 2;
+        dst[0] = (double)s1;
+        dst[1] = (double)s2;
+      }
+    }
+  }
+}
+
+// dispatch on the mode computed by the launcher (wave-uniform switch, once per tile)
+template <int NT>
+__device__ __forceinline__ void gemm16_epilogue_direct_any(const IGemm& p, f32x16 (&acc)[NT], int mw0, int n0, int M, int HW) {
+  switch (p.epi_direct) {
+    case 1: gemm16_epilogue_direct<NT, true, false, false>(p, acc, mw0, n0, M, HW); break;
+    case 2: gemm16_epilogue_direct<NT, false, true, false>(p, acc, mw0, n0, M, HW); break;
+    case 3: gemm16_epilogue_direct<NT, true, true, false>(p, acc, mw0, n0, M, HW); break;
+    case 5: gemm16_epilogue_direct<NT, true, false, true>(p, acc, mw0, n0, M, HW); break;
+    case 6: gemm16_epilogue_direct<NT, false, true, true>(p, acc, mw0, n0, M, HW); break;
+    default: gemm16_epilogue_direct<NT, true, true, true>(p, acc, mw0, n0, M, HW); break;
+  }
+}
+
 }  // namespace
 }  // namespace ddpmir

@@ -69,6 +69,9 @@ struct IGemm {
   // gemm256.hip (the 256 x 256 eight-wave tile for 3x3 convs with Cout >= 256): -1 = where it fills the chip (default),
   // 0 = never (A/B runs, parity tests against the 128-row kernel), 1 = wherever gemm256_supported() allows
   int tile256 = -1;
+  // gemm_epilogue.h, 64-column kernels: register-direct epilogue for the plain option sets (epilogue_direct_mode()); epi_direct is the
+  // mode the launcher computed (0 = LDS-transposed epilogue), epi_direct_opt = 0 forces the LDS epilogue (A/B runs, parity tests)
+  int epi_direct = 0, epi_direct_opt = 1;
   FastDiv fd_hw, fd_w;   // set by launch_gemm16: exact division by H*W and by W (pixel index -> sample, row, column)
   int dbg = 0;   // timing experiments only: 1 skip A loads, 2 skip B loads, 4 skip MFMA, 8 skip stores, 16 skip LDS writes
 };

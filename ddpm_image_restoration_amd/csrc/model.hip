@@ -639,6 +639,14 @@ void Context::set_option(const std::string& name, double value) {
     free_plan();
     return;
   }
+  if (name == "epilogue_direct") {   // 1 (default): register-direct epilogue of the 64-column GEMM kernels; 0: LDS-transposed everywhere (A/B, parity)
+    if (value != 0 && value != 1) throw std::invalid_argument("epilogue_direct must be 0 or 1");
+    epi_direct_opt_ = (int)value;
+    drop_loop_graphs();
+    if (plan_.gexec) { (void)hipGraphExecDestroy(plan_.gexec); plan_.gexec = nullptr; }
+    if (plan_.graph) { (void)hipGraphDestroy(plan_.graph); plan_.graph = nullptr; }
+    return;
+  }
   if (name == "gemm256_tile") {   // the 256 x 256 eight-wave tile for the Cout >= 256 3x3 convs: -1 where it fills the chip (default), 0 never, 1 wherever supported
     if (value != -1 && value != 0 && value != 1) throw std::invalid_argument("gemm256_tile must be -1, 0 or 1");
     tile256_opt_ = (int)value;
@@ -762,7 +770,7 @@ void Context::freq_avif(const BlockW& bw, int H, int W, hipStream_t s) {
 void Context::conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override) {
   p.Wt = nullptr; p.Wt16 = cw.w16; p.bias = bias_override ? bias_override : cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
   p.zero16 = plan_.zero16; p.splitk_ws = plan_.splitk_ws; p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
-  p.tile256 = tile256_opt_;
+  p.tile256 = tile256_opt_; p.epi_direct_opt = epi_direct_opt_;
   if (!gemm16_supported(p)) throw std::logic_error("conv16: operand layout not supported by the DMA GEMM");
   // algorithmic FLOPs: 2 M N K over the real channel counts (a stacked gate pair counts its two layers, not the zero blocks)
   const double M = (double)p.B * p.H * p.W;
@@ -775,7 +783,7 @@ void Context::conv8(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_o
   p.Wt = nullptr; p.Wt16 = cw.w8; p.bias = bias_override ? bias_override : cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
   p.f8 = 1; p.acc_scale = cw.w8_inv;
   p.zero16 = plan_.zero16; p.splitk_ws = plan_.splitk_ws; p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
-  p.tile256 = tile256_opt_;
+  p.tile256 = tile256_opt_; p.epi_direct_opt = epi_direct_opt_;
   if (!gemm16_supported(p)) throw std::logic_error("conv8: operand layout not supported by the fp8 GEMM");
   prof_begin(PROF_GEMM8, 2.0 * (double)p.B * p.H * p.W * ((double)cw.cout * cw.cin * cw.taps + (p.Cinb ? (double)cw.cout * p.Cinb : 0.0)), s);
   launch_gemm16(p, s);
@@ -1507,7 +1515,7 @@ void Context::ensure_lane() {
   if (lane_) return;
   std::unique_ptr<Context> c(new Context(cfg));
   c->is_lane_ = true;
-  c->attn_nm_bound_ = attn_nm_bound_; c->fp8_min_ch_ = fp8_min_ch_; c->stream16_opt_ = stream16_opt_; c->tile256_opt_ = tile256_opt_;
+  c->attn_nm_bound_ = attn_nm_bound_; c->fp8_min_ch_ = fp8_min_ch_; c->stream16_opt_ = stream16_opt_; c->tile256_opt_ = tile256_opt_; c->epi_direct_opt_ = epi_direct_opt_;
   c->finalize_weights(wblob_, 0);   // adopts the packed blob: same layout, no upload
   if (prof_on_) c->profile_enable(prof_detail_);
   lane_ = std::move(c);

@@ -15,6 +15,7 @@ using namespace ddpmir;
 namespace {
 thread_local std::string g_err;
 thread_local int g_bf16 = 0;
+thread_local int g_epi_direct = 1;   // IGemm::epi_direct_opt of the GEMM ops below
 thread_local int g_tile256 = -1;   // IGemm::tile256 of the GEMM ops below (-1 auto, 0 never, 1 wherever supported)
 thread_local int g_sel = 0;
 
@@ -61,6 +62,7 @@ const char* ddpmir_ops_last_error(void) { return g_err.c_str(); }
 void ddpmir_op_set_bf16(int enable) { g_bf16 = enable; }
 void ddpmir_op_set_gate_select(int C) { g_sel = C; }
 void ddpmir_op_set_tile256(int mode) { g_tile256 = mode; }
+void ddpmir_op_set_epilogue_direct(int on) { g_epi_direct = on; }
 long long ddpmir_op_gemm256_launches(void) { return gemm256_launch_count(); }
 
 int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
@@ -100,7 +102,7 @@ int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_
       p.res = d.up(res, M * Cout); p.ldres = Cout;
       float* o = d.alloc<float>(M * Cout);
       p.out = o; p.ldo = Cout; p.store = STORE_NHWC;
-      p.tile256 = g_tile256; launch_gemm16(p, nullptr);
+      p.tile256 = g_tile256; p.epi_direct_opt = g_epi_direct; launch_gemm16(p, nullptr);
       d.down(out, o, M * Cout);
       return;
     }
@@ -137,7 +139,7 @@ int ddpmir_op_conv(const float* x, int B, int H, int W, int Cin, const float* w_
       p.res = d.up(res, M * Co); p.ldres = Co;
       float* o = d.alloc<float>(M * Co);
       p.out = o; p.ldo = Co; p.store = STORE_NHWC;
-      p.tile256 = g_tile256; launch_gemm16(p, nullptr);
+      p.tile256 = g_tile256; p.epi_direct_opt = g_epi_direct; launch_gemm16(p, nullptr);
       d.down(out, o, M * Co);
       return;
     }
@@ -221,7 +223,7 @@ int ddpmir_op_conv_time(int B, int H, int W, int Cin, int Cout, int ksize, int b
     hipEvent_t a, b;
     DDPMIR_HIP_CHECK(hipEventCreate(&a));
     DDPMIR_HIP_CHECK(hipEventCreate(&b));
-    p.tile256 = g_tile256;
+    p.tile256 = g_tile256; p.epi_direct_opt = g_epi_direct;
     auto run = [&] { if (bf16 >= 2) launch_gemm16(p, nullptr); else launch_igemm(p, nullptr); };
     run();
     DDPMIR_HIP_CHECK(hipDeviceSynchronize());
@@ -263,7 +265,7 @@ int ddpmir_op_conv_gnstats_bf16(const float* x, int B, int H, int W, int Cin, co
     const size_t nw = (size_t)(H * W / 32);                    // one partial per (sample, 32-row wave tile, group)
     double* ds = d.alloc<double>(gn_sums_doubles(B, H * W, groups));
     p.gn_sums = ds; p.gn_groups = groups;
-    p.tile256 = g_tile256; launch_gemm16(p, nullptr);
+    p.tile256 = g_tile256; p.epi_direct_opt = g_epi_direct; launch_gemm16(p, nullptr);
     d.down(out, o, M * Cout);
     std::vector<double> slots(gn_sums_doubles(B, H * W, groups));
     d.down(slots.data(), ds, slots.size());
@@ -305,7 +307,7 @@ int ddpmir_op_conv_dual_bf16(const float* x1, int B, int H, int W, int C1, const
     p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); p.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
     float* o = d.alloc<float>(M * Cout);
     p.out = o; p.ldo = Cout;
-    p.tile256 = g_tile256; launch_gemm16(p, nullptr);
+    p.tile256 = g_tile256; p.epi_direct_opt = g_epi_direct; launch_gemm16(p, nullptr);
     d.down(out, o, M * Cout);
   });
 }
@@ -341,7 +343,7 @@ int ddpmir_op_conv_dual_fp8(const float* x1, int B, int H, int W, int C1, const 
     p.zero16 = d.alloc<unsigned char>(GEMM16_ZERO_BYTES); p.splitk_ws = d.alloc<float>(GEMM16_SPLITK_WS_BYTES / 4); p.splitk_ws_bytes = GEMM16_SPLITK_WS_BYTES;
     float* o = d.alloc<float>(M * Cout);
     p.out = o; p.ldo = Cout;
-    p.tile256 = g_tile256; launch_gemm16(p, nullptr);
+    p.tile256 = g_tile256; p.epi_direct_opt = g_epi_direct; launch_gemm16(p, nullptr);
     d.down(out, o, M * Cout);
   });
 }
@@ -374,7 +376,7 @@ int ddpmir_op_qkv_attention_bf16(const float* x, int B, int N, int C, int heads,
       qkv = d.alloc<float>(M * 3 * C);
       p.out = qkv; p.ldo = 3 * C;
     }
-    p.tile256 = g_tile256; launch_gemm16(p, nullptr);
+    p.tile256 = g_tile256; p.epi_direct_opt = g_epi_direct; launch_gemm16(p, nullptr);
     float* o = d.alloc<float>(M * C);
     launch_attention_bf16(qkv, o, C, B, N, C, heads, ws, nullptr);
     d.down(out, o, M * C);

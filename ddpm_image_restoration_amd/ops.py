@@ -18,6 +18,7 @@ _sigs = {
     "ddpmir_op_clock_sample_begin": (C.c_int, [C.c_double]),
     "ddpmir_op_clock_sample_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ddpmir_op_set_tile256": (None, [C.c_int]),
+    "ddpmir_op_set_epilogue_direct": (None, [C.c_int]),
     "ddpmir_op_gemm256_launches": (C.c_longlong, []),
     "ddpmir_op_conv_time": (C.c_int, [C.c_int] * 11 + [C.POINTER(C.c_float)]),
     "ddpmir_op_gn_scale_shift": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
@@ -113,6 +114,11 @@ def clock_sample_end():
 def set_tile256(mode: int):
     """IGemm::tile256 for the GEMM ops of this module: -1 auto (default), 0 never, 1 wherever gemm256_supported()."""
     _lib_ops().ddpmir_op_set_tile256(int(mode))
+
+
+def set_epilogue_direct(on: int):
+    """IGemm::epi_direct_opt for the GEMM ops of this module (1 default; 0 = LDS-transposed epilogue everywhere)."""
+    _lib_ops().ddpmir_op_set_epilogue_direct(int(on))
 
 
 def gemm256_launches() -> int:

@@ -167,6 +167,9 @@ const char* ddpmir_version(void);
  * "gemm256_tile" (-1 / 0 / 1, bf16 / fp8 modes): the 3x3 convs with >= 256 output channels on the 256 x 256 eight-wave tile
  * (csrc/gemm256.hip) -- -1 (default): where its tiles (x K splits) fill the chip; 0: never (the 128-row kernel, for A/B runs and
  * parity tests); 1: wherever the shape is supported.
+ * "epilogue_direct" (1 default / 0): the GEMM kernels with <= 64 output columns store their accumulators straight from registers
+ * (no LDS-transposed tile); 0 keeps the LDS epilogue everywhere (A/B runs; the results are bit-identical, the fused GroupNorm sums
+ * equal up to their summation order).
  * "concurrent_lanes" (-1 / 0 off, default; 1; 2): the device-codec JPEG loop in bf16 / fp8 mode splits the batch into two lanes
  * that run concurrently on two streams (a second context on the same weight blob); 2 additionally makes the full-resolution
  * attention launches of the lanes take turns.  Each lane's result equals the single-lane loop's on its half of the batch.  An

@@ -30,6 +30,8 @@ void ddpmir_op_set_bf16(int enable);
 void ddpmir_op_set_gate_select(int C);
 /* IGemm::tile256 of the GEMM ops: -1 = the 256 x 256 eight-wave tile where it fills the chip (default), 0 = never, 1 = wherever supported */
 void ddpmir_op_set_tile256(int mode);
+/* IGemm::epi_direct_opt of the GEMM ops: 1 (default) = the register-direct epilogue of the 64-column kernels where it applies, 0 = the LDS-transposed one */
+void ddpmir_op_set_epilogue_direct(int on);
 /* launches that tile has taken in this process (proof for a test that its shape did not fall back to the 128-row kernel) */
 long long ddpmir_op_gemm256_launches(void);
 /* device-resident timing of one conv/linear launch on random data (ms per call); gelu_norm adds the fused

@@ -617,3 +617,54 @@ def test_frequency_block_one_pass_kernel(ops, B, H, W, bs, low, C):
     assert int((f2 != t2).sum()) == 0
     x2 = x + O.conv2d(bf(att), bf(wo)[:, :, None, None], bo, 0)
     assert np.abs(nchw(f2) - nchw(fused)).max() > 0.05 and np.isfinite(f2).all() and np.abs(x2).max() < 50
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(2, 128, 128, 64, 64, 3), (3, 192, 224, 64, 64, 3), (1, 160, 224, 32, 32, 3), (2, 32, 32, 3, 64, 3),
+                                              (2, 16, 16, 64, 32, 1), (4, 96, 96, 128, 64, 3), (3, 128, 96, 64, 32, 3), (9, 128, 128, 64, 64, 3),
+                                              (2, 64, 64, 64, 64, 1), (5, 7, 3, 36, 40, 3), (3, 200, 232, 64, 64, 3)])
+def test_conv_bf16_register_direct_epilogue_equals_the_lds_epilogue(ops, B, H, W, Cin, Cout, k):
+    """The 64-column GEMM kernels (gemm16_kernel<1|2>, conv3x3_strip_kernel: full-resolution convs, tile walks, the tap-packed
+    image conv) store their accumulators straight from registers for the plain option sets (gemm_epilogue.h:
+    gemm16_epilogue_direct; bias, time bias, fp32 / bf16 outputs).  Same arithmetic in the same order as the LDS-transposed
+    epilogue: bit-identical results.  The last two shapes are NOT eligible (ragged column tile; H*W % 32 != 0) and must simply
+    keep working; an epilogue with factors / residual stays on the LDS path under either setting."""
+    x = rnd(B, Cin, H, W, seed=61)
+    w = rnd(Cout, Cin, k, k, seed=62, scale=1.0 / np.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=63)
+    tb, res = rnd(B, Cout, seed=64), rnd(B, Cout, H, W, seed=65)
+    try:
+        for kw in (dict(), dict(tb=tb), dict(tb=tb, res=nhwc(res))):
+            ops.set_epilogue_direct(1)
+            a = ops.conv(nhwc(x), w, b, bf16="dma", **kw)
+            ops.set_epilogue_direct(0)
+            c = ops.conv(nhwc(x), w, b, bf16="dma", **kw)
+            assert np.array_equal(a, c), (list(kw), float(np.abs(a - c).max()))
+    finally:
+        ops.set_epilogue_direct(1)
+    def bf(z):
+        u = np.ascontiguousarray(z, dtype=np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    close(nchw(a)[:1], O.conv2d(bf(x[:1]), bf(w), b, k // 2) + tb[:1, :, None, None] + res[:1], 3e-5)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,G", [(2, 128, 128, 64, 64, 3, 8), (2, 128, 128, 8, 32, 3, 8), (4, 64, 128, 64, 64, 3, 1), (2, 128, 128, 32, 64, 3, 4),
+                                                (8, 64, 64, 16, 32, 1, 2), (2, 128, 128, 64, 64, 3, 2)])
+def test_conv_bf16_register_direct_epilogue_groupnorm_statistics(ops, B, H, W, Cin, Cout, k, G):
+    """the direct epilogue's per-(sample, group) sums (one writer per 32-row block and group; groups of 4 ... 64 channels, a
+    64-channel group spanning both column tiles) are the statistics of the tensor it stored and equal the LDS epilogue's up to
+    the summation order."""
+    x = rnd(B, Cin, H, W, seed=70)
+    w = rnd(Cout, Cin, k, k, seed=71, scale=1.0 / np.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=72) + 0.5
+    try:
+        ops.set_epilogue_direct(1)
+        out, sums = ops.conv_gnstats_bf16(nhwc(x), w, b, G)
+        ops.set_epilogue_direct(0)
+        out0, sums0 = ops.conv_gnstats_bf16(nhwc(x), w, b, G)
+    finally:
+        ops.set_epilogue_direct(1)
+    assert np.array_equal(out, out0)
+    o = out.astype(np.float64).reshape(B, H * W, G, Cout // G)
+    want = np.stack([o.sum(axis=(1, 3)), (o * o).sum(axis=(1, 3))], axis=-1)
+    assert np.allclose(sums, want, rtol=2e-5, atol=1e-2), np.abs(sums - want).max()
+    assert np.allclose(sums, sums0, rtol=2e-5, atol=1e-2)
