@@ -211,6 +211,11 @@ void launch_cl_boost(const float* cl, int B, float a0, float a1, float lo, float
 void launch_nchw3_to_nhwc4(const float* in, float* out, int B, int H, int W, hipStream_t s);
 // [B*H*W][4] fp32 -> tanh -> [B][3][H][W]
 void launch_nhwc4_to_nchw3_tanh(const float* in, float* out, int B, int H, int W, hipStream_t s);
+// head_fused.hip: tanh(conv3x3_{64->3}(SiLU(x * scale + shift)) + bias) in one pass over x [B*H*W][ldx] (fp32, or bf16 when in16);
+// w16 = the packed head conv [9][4][64] bf16; out NCHW fp32.  H % 8 == 0 and W % 32 == 0.
+bool head_fused_supported(int H, int W);
+void launch_head_fused(const void* x, int ldx, bool in16, const float* scale, const float* shift, const void* w16, const float* bias,
+                       float* out, int B, int H, int W, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------ sampler
 // u8 = uint8(trunc(clamp(x*127.5+127.5, 0, 255)))  (two roundings, no fma)   webp_inference.py:509

@@ -239,6 +239,7 @@ class Context {
   void conv8(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override = nullptr);   // e4m3 operands (p.A16 = e4m3 tensor)
   int tile256_opt_ = -1;    // option "gemm256_tile" (IGemm::tile256)
   int epi_direct_opt_ = 1;  // option "epilogue_direct" (IGemm::epi_direct_opt)
+  int head_fused_opt_ = 1;  // option "head_fused"
   int fp8_min_ch_ = 256;    // DDPMIR_FP8: 3x3 convs with at least this many input AND output channels take e4m3 operands
   void freq_dct(const BlockW& bw, int H, int W, hipStream_t s);
   void freq_avif(const BlockW& bw, int H, int W, hipStream_t s);

@@ -647,6 +647,14 @@ void Context::set_option(const std::string& name, double value) {
     if (plan_.graph) { (void)hipGraphDestroy(plan_.graph); plan_.graph = nullptr; }
     return;
   }
+  if (name == "head_fused") {   // 1 (default): the output head in one pass (head_fused.hip); 0: GroupNorm-apply pass + strip conv + tanh pass
+    if (value != 0 && value != 1) throw std::invalid_argument("head_fused must be 0 or 1");
+    head_fused_opt_ = (int)value;
+    drop_loop_graphs();
+    if (plan_.gexec) { (void)hipGraphExecDestroy(plan_.gexec); plan_.gexec = nullptr; }
+    if (plan_.graph) { (void)hipGraphDestroy(plan_.graph); plan_.graph = nullptr; }
+    return;
+  }
   if (name == "gemm256_tile") {   // the 256 x 256 eight-wave tile for the Cout >= 256 3x3 convs: -1 where it fills the chip (default), 0 never, 1 wherever supported
     if (value != -1 && value != 0 && value != 1) throw std::invalid_argument("gemm256_tile must be -1, 0 or 1");
     tile256_opt_ = (int)value;
@@ -1181,7 +1189,12 @@ void Context::fwd_tail(float* out, int row0, int nb, bool whole, hipStream_t s) 
                             head_g_, head_b_, p.sc1, p.sh1, s);
   else
     launch_gn_scale_shift(p.S, 64, nb, H * W, 64, 8, head_g_, head_b_, p.gn_partial, p.sc1, p.sh1, s);
-  if (use_gemm16()) {   // SiLU(GN(.)) as a bf16 operand -> DMA GEMM with Cout padded to 4 -> tanh + NCHW in one pass
+  if (use_gemm16() && head_fused_opt_ && head_fused_supported(H, W) && head_conv_.w16 && head_conv_.cout16 == 4 && head_conv_.cin16 == 64) {
+    // one pass: GroupNorm-apply + SiLU + conv 64 -> 3 + tanh + NCHW (head_fused.hip) instead of three launches
+    prof_begin(PROF_GEMM, 2.0 * (double)nb * H * W * 3 * 64 * 9, s);
+    launch_head_fused(u0a.h ? (const void*)p.S16 : (const void*)p.S, 64, u0a.h, p.sc1, p.sh1, head_conv_.w16, head_conv_.b, out, nb, H, W, s);
+    prof_end(s);
+  } else if (use_gemm16()) {   // SiLU(GN(.)) as a bf16 operand -> DMA GEMM with Cout padded to 4 -> tanh + NCHW in one pass
     float* x4 = p.x4 + (size_t)row0 * HW * 4;          // the lane's image rows are free again
     launch_gn_apply16(u0a.h ? nullptr : p.S, 64, nb, H * W, 64, p.sc1, p.sh1, ACT_SILU, p.a16, 64, nullptr, 0, s, nullptr, 0, nullptr, 0,
                       u0a.h ? p.S16 : nullptr);
@@ -1515,7 +1528,7 @@ void Context::ensure_lane() {
   if (lane_) return;
   std::unique_ptr<Context> c(new Context(cfg));
   c->is_lane_ = true;
-  c->attn_nm_bound_ = attn_nm_bound_; c->fp8_min_ch_ = fp8_min_ch_; c->stream16_opt_ = stream16_opt_; c->tile256_opt_ = tile256_opt_; c->epi_direct_opt_ = epi_direct_opt_;
+  c->attn_nm_bound_ = attn_nm_bound_; c->fp8_min_ch_ = fp8_min_ch_; c->stream16_opt_ = stream16_opt_; c->tile256_opt_ = tile256_opt_; c->epi_direct_opt_ = epi_direct_opt_; c->head_fused_opt_ = head_fused_opt_;
   c->finalize_weights(wblob_, 0);   // adopts the packed blob: same layout, no upload
   if (prof_on_) c->profile_enable(prof_detail_);
   lane_ = std::move(c);

@@ -847,3 +847,30 @@ def test_two_concurrent_lanes_equal_the_lanes_run_one_after_the_other(dtype, siz
     odd = s.sample(y[:3], q, steps=3, seed=1)
     m.set_option("concurrent_lanes", 0)
     assert torch.equal(odd, s.sample(y[:3], q, steps=3, seed=1))
+
+
+@pytest.mark.parametrize("arch,dtype,stream16", [(spec.ARCH_JPEG, "bf16", -1), (spec.ARCH_JPEG, "bf16", 1), (spec.ARCH_JPEG, "fp8", -1), (spec.ARCH_WEBP, "bf16", -1),
+                                                 (spec.ARCH_AVIF, "bf16", -1)])
+def test_output_head_in_one_pass_equals_the_three_launches(arch, dtype, stream16, synth_state):
+    """head_fused.hip: GroupNorm-apply + SiLU + conv 64 -> 3 + tanh + NCHW as ONE kernel (halo tile through registers into LDS, one
+    MFMA chain per tile row) against the generic path it replaces (gn_apply16 pass, strip conv with the 3 outputs padded to 32
+    columns, layout pass): the same bf16 operand and the same products, fp32 accumulation in another order -> agreement to a few
+    ulps of the pre-tanh sum; image borders (zero padding of the ACTIVATED tensor), fp32 and bf16 input (the bf16 activation
+    stream), several tiles per image and a non-square image."""
+    import torch
+    from ddpm_image_restoration_amd.model import MODEL_BY_ARCH
+    m = MODEL_BY_ARCH[arch](device=torch.device("cuda", 0), dtype=dtype, attn_levels="bottleneck")
+    if stream16 >= 0:
+        m.set_option("bf16_activation_stream", stream16)
+    m.load_state_dict(synth_state(arch))
+    for (B, H, W) in ((2, 32, 32), (3, 64, 96), (1, 128, 64)):
+        x = torch.from_numpy(synth.synth_images(B, max(H, W), seed=17)[:, :, :H, :W].copy()).cuda()
+        t = torch.linspace(0.1, 0.9, B, device="cuda")
+        m.set_option("head_fused", 1)
+        a = m(x, t, t)
+        assert torch.equal(m(x, t, t), a)
+        m.set_option("head_fused", 0)
+        b = m(x, t, t)
+        d = float((a - b).abs().max())
+        assert torch.isfinite(a).all() and d < 2e-5, (arch, dtype, (B, H, W), d)
+        assert float(a.abs().max()) > 1e-3
