@@ -9,9 +9,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libddpmir.so")
-SOURCES = ["igemm.hip", "gemm16.hip", "gemm256.hip", "attention.hip", "attention_bf16.hip", "pointwise.hip", "freq_fused.hip", "head_fused.hip", "sampler_kernels.hip", "jpeg_sim.hip", "model.hip", "eps_unet.hip", "api.hip", "ops_api.hip", "host_codec.cpp"]
+SOURCES = ["igemm.hip", "gemm16.hip", "gemm256.hip", "attention.hip", "attention_bf16.hip", "pointwise.hip", "freq_fused.hip", "head_fused.hip", "conv_tile.hip", "sampler_kernels.hip", "jpeg_sim.hip", "model.hip", "eps_unet.hip", "api.hip", "ops_api.hip", "host_codec.cpp"]
 # MFMA results feed VALU (softmax) directly: keep C/D in VGPRs instead of copying through AGPRs every tile
-VGPR_MFMA = {"attention_bf16.hip", "attention.hip", "gemm16.hip", "gemm256.hip", "freq_fused.hip", "head_fused.hip"}
+VGPR_MFMA = {"attention_bf16.hip", "attention.hip", "gemm16.hip", "gemm256.hip", "freq_fused.hip", "head_fused.hip", "conv_tile.hip"}
 # packed-f32 VALU (v_pk_add_f32) beside MFMAs costs ~3x a scalar add on gfx950: keep the softmax sums scalar
 NO_SLP = {"attention_bf16.hip"}
 NO_CONTRACT = {"sampler_kernels.hip"}   # bit-exact uint8 truncation path: no fma contraction

@@ -813,18 +813,6 @@ __global__ void splitk_reduce_k(const IGemm p, int nsplit, int64_t M, int HW) {
   }
 }
 
-// GELU for a result that is rounded to bf16: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, three orders below the bf16
-// rounding step) -- one v_rcp_f32, one v_exp_f32 and seven FMAs instead of ocml's erff (~45 instructions).  The norm2-apply pass
-// over a full-resolution tensor was bound by exactly that arithmetic (134 M elements: 156 us for 537 MB, 3.4 TB/s).
-__device__ __forceinline__ float gelu_bf16_grade(float v) {
-  const float x = fabsf(v) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-  const float e = 1.0f - poly * __expf(-x * x);
-  return 0.5f * v * (1.0f + copysignf(e, v));
-}
-__device__ __forceinline__ float act16(float v, int act) { return act == ACT_GELU ? gelu_bf16_grade(v) : act_apply(v, act); }
-
 // fp32 [M][ldx] -> bf16 [M][ld16] with the GroupNorm affine + activation of the consuming conv applied once
 // (x*scale[b][c] + shift[b][c], then act); optionally also a raw bf16 copy (input of the 1x1 shortcut conv).
 // Large tensors (every thread has work in every sample): a thread keeps its 8-channel slot, walks sample by sample with its

@@ -211,6 +211,12 @@ void launch_cl_boost(const float* cl, int B, float a0, float a1, float lo, float
 void launch_nchw3_to_nhwc4(const float* in, float* out, int B, int H, int W, hipStream_t s);
 // [B*H*W][4] fp32 -> tanh -> [B][3][H][W]
 void launch_nhwc4_to_nchw3_tanh(const float* in, float* out, int B, int H, int W, hipStream_t s);
+// conv_tile.hip: out = conv3x3(act(x * scale[b][c] + shift[b][c])) + epilogue, the GroupNorm-apply pass fused into a full-resolution
+// 3x3 conv with 64 output channels; p = the conv as launch_gemm16 would get it minus its A operand; x = the RAW tensor [B*H*W][ldx]
+// (fp32, or bf16 when in16); raw16 != null: also writes a bf16 copy of x (the 1x1 shortcut's operand)
+bool conv_tile_supported(const IGemm& p);
+void launch_conv_tile(const IGemm& p, const void* x, int ldx, bool in16, const float* scale, const float* shift, int act, void* raw16,
+                      int ldraw, hipStream_t s);
 // head_fused.hip: tanh(conv3x3_{64->3}(SiLU(x * scale + shift)) + bias) in one pass over x [B*H*W][ldx] (fp32, or bf16 when in16);
 // w16 = the packed head conv [9][4][64] bf16; out NCHW fp32.  H % 8 == 0 and W % 32 == 0.
 bool head_fused_supported(int H, int W);

@@ -240,6 +240,9 @@ class Context {
   int tile256_opt_ = -1;    // option "gemm256_tile" (IGemm::tile256)
   int epi_direct_opt_ = 1;  // option "epilogue_direct" (IGemm::epi_direct_opt)
   int head_fused_opt_ = 1;  // option "head_fused"
+  int conv_tile_opt_ = 1;   // option "conv_tile"
+  bool conv_tile_try(const ConvW& cw, IGemm p, const void* x, int ldx, bool in16, const float* scale, const float* shift, int act,
+                     void* raw16, int ldraw, hipStream_t s);
   int fp8_min_ch_ = 256;    // DDPMIR_FP8: 3x3 convs with at least this many input AND output channels take e4m3 operands
   void freq_dct(const BlockW& bw, int H, int W, hipStream_t s);
   void freq_avif(const BlockW& bw, int H, int W, hipStream_t s);

@@ -655,6 +655,14 @@ void Context::set_option(const std::string& name, double value) {
     if (plan_.graph) { (void)hipGraphDestroy(plan_.graph); plan_.graph = nullptr; }
     return;
   }
+  if (name == "conv_tile") {   // GroupNorm-apply fused into the full-resolution 64 -> 64 3x3 convs (conv_tile.hip): 1 (default) from 1.5 M pixels, 2 always, 0 never
+    if (value != 0 && value != 1 && value != 2) throw std::invalid_argument("conv_tile must be 0, 1 or 2");
+    conv_tile_opt_ = (int)value;
+    drop_loop_graphs();
+    if (plan_.gexec) { (void)hipGraphExecDestroy(plan_.gexec); plan_.gexec = nullptr; }
+    if (plan_.graph) { (void)hipGraphDestroy(plan_.graph); plan_.graph = nullptr; }
+    return;
+  }
   if (name == "gemm256_tile") {   // the 256 x 256 eight-wave tile for the Cout >= 256 3x3 convs: -1 where it fills the chip (default), 0 never, 1 wherever supported
     if (value != -1 && value != 0 && value != 1) throw std::invalid_argument("gemm256_tile must be -1, 0 or 1");
     tile256_opt_ = (int)value;
@@ -787,6 +795,23 @@ void Context::conv16(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_
   prof_end(s);
 }
 
+// GroupNorm-apply + activation fused into a full-resolution 3x3 conv (conv_tile.hip) when the shape and the epilogue allow it
+bool Context::conv_tile_try(const ConvW& cw, IGemm p, const void* x, int ldx, bool in16, const float* scale, const float* shift, int act,
+                            void* raw16, int ldraw, hipStream_t s) {
+  if (!conv_tile_opt_ || !cw.w16 || cw.is_f8) return false;
+  // measured (tools/option_ab.py conv_tile, profiles/r04_conv_tile_ab.txt): -0.09 ... -0.16 ms of a 512 x 512, B = 8 timestep
+  // (2.1 M pixels), +0.07 ms at 256 x 256, B = 16 (1.05 M): the persistent kernel's weight prologue and its GELU-bound loaders
+  // need the longer tile walk.  1 = that policy, 2 = wherever supported.
+  if (conv_tile_opt_ == 1 && (int64_t)p.B * p.H * p.W < 1500000) return false;
+  p.Wt = nullptr; p.Wt16 = cw.w16; p.bias = cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
+  p.A16 = nullptr;
+  if (!conv_tile_supported(p)) return false;
+  prof_begin(PROF_GEMM, 2.0 * (double)p.B * p.H * p.W * (double)cw.cout * cw.cin * cw.taps, s);
+  launch_conv_tile(p, x, ldx, in16, scale, shift, act, raw16, ldraw, s);
+  prof_end(s);
+  return true;
+}
+
 void Context::conv8(const ConvW& cw, IGemm p, hipStream_t s, const float* bias_override) {
   p.Wt = nullptr; p.Wt16 = cw.w8; p.bias = bias_override ? bias_override : cw.b; p.Cout = cw.cout16; p.Cin = cw.cin16; p.taps = cw.taps;
   p.f8 = 1; p.acc_scale = cw.w8_inv;
@@ -862,9 +887,6 @@ void Context::run_block16(const BlockW& bw, ActBuf in, int H, int W, ActBuf dest
   if (fuse_gn) launch_gn_from_sums(p.gn_sums, B, HW, C, gn_groups(C), bw.n2g, bw.n2b, p.sc2, p.sh2, s);
   else launch_gn_scale_shift(p.hA, C, B, HW, C, gn_groups(C), bw.n2g, bw.n2b, p.gn_partial, p.sc2, p.sh2, s);
   STAGE("norm2 statistics");
-  launch_gn_apply16(p.hA, C, B, HW, C, p.sc2, p.sh2, ACT_GELU, c2_f8 ? nullptr : p.a16, C, nullptr, 0, s, nullptr, 0,
-                    c2_f8 ? p.a8 : nullptr, C, ha16 ? p.hid16 : nullptr);
-  STAGE("norm2 apply + GELU");
   const bool attn = bw.level >= cfg.attn_min_level;
   // 64- and 128-channel blocks of the DCT families: DCT, both gate layers and S = x + g * xd run as one pass over x
   const bool fuse_freq = cfg.arch != DDPMIR_ARCH_AVIF && !exp_switch("DDPMIR_SPLIT_GATES") && !exp_switch("DDPMIR_NO_FREQ_FUSE") &&
@@ -874,9 +896,17 @@ void Context::run_block16(const BlockW& bw, ActBuf in, int H, int W, ActBuf dest
   const bool hb16_only = fuse_freq && (!attn || C == 64) && !exp_switch("DDPMIR_HB_FP32");
   IGemm c2 = g; c2.A16 = p.a16; c2.lda16 = C; c2.out = hb16_only ? nullptr : p.hB; c2.ldo = C;
   if (attn || hb16_only) { c2.out16 = p.hB16; c2.ldo16 = C; }
-  if (c2_f8) { c2.A16 = p.a8; conv8(bw.conv2, c2, s); }
-  else conv16(bw.conv2, c2, s);
-  STAGE("conv2");
+  // full-resolution blocks: norm2 + GELU are applied inside the conv (conv_tile.hip) -- no operand pass, the raw tensor is read once
+  if (!c2_f8 && conv_tile_try(bw.conv2, c2, ha16 ? (const void*)p.hid16 : (const void*)p.hA, C, ha16, p.sc2, p.sh2, ACT_GELU, nullptr, 0, s)) {
+    STAGE("norm2 + GELU + conv2 (one kernel)");
+  } else {
+    launch_gn_apply16(p.hA, C, B, HW, C, p.sc2, p.sh2, ACT_GELU, c2_f8 ? nullptr : p.a16, C, nullptr, 0, s, nullptr, 0,
+                      c2_f8 ? p.a8 : nullptr, C, ha16 ? p.hid16 : nullptr);
+    STAGE("norm2 apply + GELU");
+    if (c2_f8) { c2.A16 = p.a8; conv8(bw.conv2, c2, s); }
+    else conv16(bw.conv2, c2, s);
+    STAGE("conv2");
+  }
   if (attn) {
     // head_dim 16 levels: the projection's epilogue writes the attention operand images itself (no fp32 qkv round trip)
     const bool no_fuse = exp_switch("DDPMIR_NO_QKV_FUSE");
@@ -1528,7 +1558,7 @@ void Context::ensure_lane() {
   if (lane_) return;
   std::unique_ptr<Context> c(new Context(cfg));
   c->is_lane_ = true;
-  c->attn_nm_bound_ = attn_nm_bound_; c->fp8_min_ch_ = fp8_min_ch_; c->stream16_opt_ = stream16_opt_; c->tile256_opt_ = tile256_opt_; c->epi_direct_opt_ = epi_direct_opt_; c->head_fused_opt_ = head_fused_opt_;
+  c->attn_nm_bound_ = attn_nm_bound_; c->fp8_min_ch_ = fp8_min_ch_; c->stream16_opt_ = stream16_opt_; c->tile256_opt_ = tile256_opt_; c->epi_direct_opt_ = epi_direct_opt_; c->head_fused_opt_ = head_fused_opt_; c->conv_tile_opt_ = conv_tile_opt_;
   c->finalize_weights(wblob_, 0);   // adopts the packed blob: same layout, no upload
   if (prof_on_) c->profile_enable(prof_detail_);
   lane_ = std::move(c);

@@ -278,6 +278,67 @@ int ddpmir_op_conv_gnstats_bf16(const float* x, int B, int H, int W, int Cin, co
   });
 }
 
+int ddpmir_op_conv_tile(const float* x, int B, int H, int W, int Cin, int in16, const float* scale, const float* shift, int act,
+                        const float* w_oihw, const float* bias, const float* tb, int Cout, int groups, int want16, float* out, float* out16f,
+                        double* sums, float* raw16f) {
+  return guarded([&] {
+    Dev d;
+    const size_t M = (size_t)B * H * W;
+    auto bf = [](float f) {
+      unsigned int u;
+      memcpy(&u, &f, 4);
+      return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    };
+    auto unbf = [](unsigned short h) { unsigned int u = (unsigned int)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    std::vector<unsigned short> wa((size_t)9 * Cout * Cin, 0);
+    for (int o = 0; o < Cout; ++o)
+      for (int c = 0; c < Cin; ++c)
+        for (int t = 0; t < 9; ++t) wa[((size_t)t * Cout + o) * Cin + c] = bf(w_oihw[((size_t)o * Cin + c) * 9 + t]);
+    IGemm p;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.taps = 9; p.bias = d.up(bias, Cout);
+    p.Wt16 = d.up(wa.data(), wa.size());
+    if (tb) { p.tb = d.up(tb, (size_t)B * Cout); p.ldtb = Cout; }
+    float* o32 = out ? d.alloc<float>(M * Cout) : nullptr;
+    unsigned short* o16 = want16 ? d.alloc<unsigned short>(M * Cout + 8) : nullptr;
+    p.out = o32; p.ldo = Cout; p.out16 = o16; p.ldo16 = Cout;
+    double* ds = nullptr;
+    if (groups > 0) { ds = d.alloc<double>(gn_sums_doubles(B, H * W, groups)); p.gn_sums = ds; p.gn_groups = groups; }
+    const void* xin;
+    if (in16) {
+      std::vector<unsigned short> xa(M * Cin);
+      for (size_t i = 0; i < xa.size(); ++i) xa[i] = bf(x[i]);
+      xin = d.up(xa.data(), xa.size());
+    } else {
+      xin = d.up(x, M * Cin);
+    }
+    unsigned short* r16 = raw16f ? d.alloc<unsigned short>(M * Cin + 8) : nullptr;
+    if (!conv_tile_supported(p)) throw std::runtime_error("conv_tile: unsupported shape or epilogue");
+    launch_conv_tile(p, xin, Cin, in16 != 0, scale ? d.up(scale, (size_t)B * Cin) : nullptr, shift ? d.up(shift, (size_t)B * Cin) : nullptr, act, r16, Cin, nullptr);
+    if (out) d.down(out, o32, M * Cout);
+    if (want16) {
+      std::vector<unsigned short> h(M * Cout);
+      d.down(h.data(), o16, h.size());
+      for (size_t i = 0; i < h.size(); ++i) out16f[i] = unbf(h[i]);
+    }
+    if (raw16f) {
+      std::vector<unsigned short> h(M * Cin);
+      d.down(h.data(), r16, h.size());
+      for (size_t i = 0; i < h.size(); ++i) raw16f[i] = unbf(h[i]);
+    }
+    if (groups > 0) {
+      const size_t nw = (size_t)(H * W / 32);
+      std::vector<double> slots(gn_sums_doubles(B, H * W, groups));
+      d.down(slots.data(), ds, slots.size());
+      for (int b = 0; b < B; ++b)
+        for (int g = 0; g < groups * 2; ++g) {
+          double t = 0.0;
+          for (size_t sl = 0; sl < nw; ++sl) t += slots[((size_t)b * nw + sl) * groups * 2 + g];
+          sums[(size_t)b * groups * 2 + g] = t;
+        }
+    }
+  });
+}
+
 int ddpmir_op_conv_dual_bf16(const float* x1, int B, int H, int W, int C1, const float* w1_oihw, int ksize, const float* x2,
                              int C2, const float* w2_oi, const float* bias, int Cout, float* out) {
   return guarded([&] {

@@ -27,6 +27,7 @@ _sigs = {
     "ddpmir_op_attention_bf16_ex": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
     "ddpmir_op_conv_gnstats_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "ddpmir_op_conv_dual_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "ddpmir_op_conv_tile": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "ddpmir_op_conv_dual_fp8": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "ddpmir_op_qkv_attention_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "ddpmir_op_attention_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
@@ -189,6 +190,22 @@ def conv_dual_bf16(x1, w1, x2, w2, bias):
     _chk(lib, lib.ddpmir_op_conv_dual_bf16(_p(x1), b, h, wd, c1, _p(w1), k, _p(x2), x2.shape[-1], _p(w2), _p(bias), cout,
                                            _p(out)), "op_conv_dual")
     return out
+
+
+def conv_tile(x, w, bias, scale=None, shift=None, act=None, tb=None, groups=0, in16=False, want32=True, want16=False, want_raw=False):
+    """conv3x3(act(x * scale + shift)) + bias (+ tb) with the norm-apply pass fused into the conv (conv_tile.hip); NHWC in/out.
+    Returns a dict with the requested outputs: out, out16, sums, raw16."""
+    lib = _lib_ops()
+    x, w, bias, scale, shift, tb = _f(x), _f(w), _f(bias), _f(scale), _f(shift), _f(tb)
+    b, h, wd, cin = x.shape
+    cout = w.shape[0]
+    out = np.empty((b, h, wd, cout), np.float32) if want32 else None
+    out16 = np.empty((b, h, wd, cout), np.float32) if want16 else None
+    sums = np.empty((b, groups, 2), np.float64) if groups else None
+    raw = np.empty((b, h, wd, cin), np.float32) if want_raw else None
+    _chk(lib, lib.ddpmir_op_conv_tile(_p(x), b, h, wd, cin, int(in16), _p(scale), _p(shift), ACT[act], _p(w), _p(bias), _p(tb), cout, int(groups),
+                                      int(want16), _p(out), _p(out16), sums.ctypes.data_as(C.c_void_p) if groups else None, _p(raw)), "op_conv_tile")
+    return {"out": out, "out16": out16, "sums": sums, "raw16": raw}
 
 
 def conv_dual_fp8(x1, w1, x2, w2, bias):

@@ -170,6 +170,9 @@ const char* ddpmir_version(void);
  * "epilogue_direct" (1 default / 0): the GEMM kernels with <= 64 output columns store their accumulators straight from registers
  * (no LDS-transposed tile); 0 keeps the LDS epilogue everywhere (A/B runs; the results are bit-identical, the fused GroupNorm sums
  * equal up to their summation order).
+ * "conv_tile" (0 / 1 default / 2): GroupNorm-apply (+ GELU) fused into the full-resolution 64 -> 64 3x3 convs (conv_tile.hip: the raw
+ * tensor is read once, no bf16 operand pass) -- 1: from 1.5 M pixels per launch (where it measured faster), 2: wherever supported,
+ * 0: operand pass + DMA GEMM.
  * "head_fused" (1 default / 0): the output head (GroupNorm-apply + SiLU + conv 64 -> 3 + tanh + NCHW) as one kernel; 0: three launches.
  * "concurrent_lanes" (-1 / 0 off, default; 1; 2): the device-codec JPEG loop in bf16 / fp8 mode splits the batch into two lanes
  * that run concurrently on two streams (a second context on the same weight blob); 2 additionally makes the full-resolution

@@ -55,6 +55,13 @@ int ddpmir_op_attention_bf16_ex(const float* qkv, int B, int N, int C, int heads
  * nn.GroupNorm, webp_inference.py:290): sums [B][groups][2] = (sum, sum of squares) per sample and group. */
 int ddpmir_op_conv_gnstats_bf16(const float* x, int B, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
                                 int ksize, int groups, float* out, double* sums);
+/* conv_tile.hip: out = conv3x3(act(x * scale[b][c] + shift[b][c])) + bias (+ tb[b][n]) with the GroupNorm-apply pass fused into the
+ * conv (webp_inference.py:306-313).  x [B,H,W,Cin] (rounded to bf16 first when in16), Cout = 64, Cin % 64 == 0, H % 8 == 0, W % 32 == 0;
+ * scale / shift / tb may be NULL; groups > 0: also the per-(sample, group) sums of the stored output [B][groups][2]; out (fp32) and / or
+ * out16f (the bf16 copy, widened) ; raw16f != NULL: the bf16 copy of x the kernel writes for the 1x1 shortcut, widened. */
+int ddpmir_op_conv_tile(const float* x, int B, int H, int W, int Cin, int in16, const float* scale, const float* shift, int act,
+                        const float* w_oihw, const float* bias, const float* tb, int Cout, int groups, int want16, float* out, float* out16f,
+                        double* sums, float* raw16f);
 /* out = conv_kxk(x1, w1) + conv_1x1(x2, w2) + bias in ONE DMA-GEMM launch (second K segment): conv_out with the block's
  * 1x1 shortcut folded in (webp_inference.py:326-327).  x1 [B,H,W,C1], x2 [B,H,W,C2], out [B,H,W,Cout]. */
 int ddpmir_op_conv_dual_bf16(const float* x1, int B, int H, int W, int C1, const float* w1_oihw, int ksize, const float* x2,
