@@ -15,6 +15,8 @@
 // v_mfma_f32_32x32x16_bf16 chain over K = 9 taps x 64 channels with A = the weights (32 "rows" of which 3 are real; the others
 // read a zero row) and B = the row's 32 pixels shifted by the tap, so lane lr < 32 ends with its pixel's three outputs in
 // acc[0..2].  Epilogue: + bias, tanh, three coalesced 128-byte row stores into the NCHW image.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace ddpmir {
@@ -47,33 +49,43 @@ __global__ __launch_bounds__(256) void head_fused_k(const void* __restrict__ xin
     if (row < 4) v = *reinterpret_cast<const bf16x8*>(w16 + ((size_t)tap * 4 + row) * 64 + ch * 8);
     *reinterpret_cast<bf16x8*>(wl + (tap * WROWS + row) * 128 + ch * 16) = v;
   }
-  // ---- activated halo tile
-  for (int i = tid; i < PH * PW * 8; i += 256) {
-    const int p = i >> 3, ch = i & 7;
-    const int py = p / PW, px = p - py * PW;
-    const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
-    bf16x8 o;
+  // ---- activated halo tile.  A thread's pieces (8 channels of one pixel) are 256 apart: the same channel chunk for all of them, so
+  // scale / shift are fetched once; all of a thread's loads are issued before the first is used (a loop that waits for each load
+  // in turn is 11 dependent memory round trips per tile).
+  {
+    constexpr int NPIECE = PH * PW * 8, NI = (NPIECE + 255) / 256;
+    const int ch = tid & 7, c = ch * 8;
+    const float4 s0 = *reinterpret_cast<const float4*>(scale + (size_t)b * 64 + c), s1 = *reinterpret_cast<const float4*>(scale + (size_t)b * 64 + c + 4);
+    const float4 f0 = *reinterpret_cast<const float4*>(shift + (size_t)b * 64 + c), f1 = *reinterpret_cast<const float4*>(shift + (size_t)b * 64 + c + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    typename std::conditional<IN16, bf16x8, f32x8>::type raw[NI];
+    unsigned inside = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (__bf16)0.f;
-    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-      const size_t m = img + (size_t)gy * W + gx;
-      float r[8];
-      if (IN16) {
-        const bf16x8 t = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(xin) + m * ldx + ch * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (float)t[j];
-      } else {
-        const float4 t0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xin) + m * ldx + ch * 8);
-        const float4 t1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xin) + m * ldx + ch * 8 + 4);
-        r[0] = t0.x; r[1] = t0.y; r[2] = t0.z; r[3] = t0.w; r[4] = t1.x; r[5] = t1.y; r[6] = t1.z; r[7] = t1.w;
+    for (int it = 0; it < NI; ++it) {
+      const int i = tid + it * 256, p = i >> 3;
+      const int py = p / PW, px = p - py * PW;
+      const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+      if (i < NPIECE && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+        inside |= 1u << it;
+        const size_t m = img + (size_t)gy * W + gx;
+        if constexpr (IN16) raw[it] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(xin) + m * ldx + c);
+        else raw[it] = *reinterpret_cast<const f32x8*>(reinterpret_cast<const float*>(xin) + m * ldx + c);
       }
-      const float4 s0 = *reinterpret_cast<const float4*>(scale + (size_t)b * 64 + ch * 8), s1 = *reinterpret_cast<const float4*>(scale + (size_t)b * 64 + ch * 8 + 4);
-      const float4 f0 = *reinterpret_cast<const float4*>(shift + (size_t)b * 64 + ch * 8), f1 = *reinterpret_cast<const float4*>(shift + (size_t)b * 64 + ch * 8 + 4);
-      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (__bf16)act_apply(fmaf(r[j], sc[j], sh[j]), ACT_SILU);   // = gn_apply16_k's operand
     }
-    *reinterpret_cast<bf16x8*>(lds + p * 128 + ((ch ^ ((p >> 1) & 7)) << 4)) = o;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int i = tid + it * 256, p = i >> 3;
+      if (i >= NPIECE) continue;
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (__bf16)0.f;
+      if (inside & (1u << it)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)act_apply(fmaf((float)raw[it][j], sc[j], sh[j]), ACT_SILU);   // = gn_apply16_k's operand
+      }
+      *reinterpret_cast<bf16x8*>(lds + p * 128 + ((ch ^ ((p >> 1) & 7)) << 4)) = o;
+    }
   }
   __syncthreads();
   // ---- 2 tile rows per wave, one MFMA chain each
