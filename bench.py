@@ -226,7 +226,7 @@ def run_workload(w: dict, env, dev, K: int, W: int, full: bool = False, graph: i
         variant = dtype + ("@%d" % fmc if fmc not in (None, 256) else "") + ("+stream16" if s16 == 1 else "")
         traffic, tsrc = committed_traffic(f"{arch_name}_{variant}_{R}_B{B}_{attn}", lib_src_hash(det["version"]))
         roof = {"bound": "mfma", "kernel": "GEMM class: all %d launches per forward of the DMA-streamed implicit-GEMM kernels (3x3 / 1x1 convolutions, "
-                                           "projections; gemm16_kernel / gemm256_kernel / conv3x3_strip_kernel / splitk_reduce_k)" % round(gemm["launches_per_forward"]),
+                                           "projections; gemm16_kernel / gemm256_kernel / conv3x3_strip_kernel / conv_tile_kernel / head_fused_k / splitk_reduce_k)" % round(gemm["launches_per_forward"]),
                 "achieved": gemm["all"]["achieved"], "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": gemm["all"]["frac_of_bf16_peak"],
                 "traffic": traffic, "traffic_source": tsrc, "per_launch": "one forward's GEMM launches (sum of 2*M*N*K / sum of event times)",
                 "gemm_ms_per_forward": gemm["ms_per_forward"], "bf16_launches": gemm["bf16"],

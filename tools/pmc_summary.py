@@ -71,7 +71,7 @@ if "--json" in sys.argv:
     key = sys.argv[sys.argv.index("--key") + 1]
     cmd = sys.argv[sys.argv.index("--command") + 1] if "--command" in sys.argv else None
     if "--class" in sys.argv and sys.argv[sys.argv.index("--class") + 1] == "gemm":
-        sel = [k for k in fe if ("gemm16_kernel" in k or "gemm256_kernel" in k or "conv3x3_strip" in k or "splitk_reduce" in k)]
+        sel = [k for k in fe if ("gemm16_kernel" in k or "gemm256_kernel" in k or "conv3x3_strip" in k or "splitk_reduce" in k or "conv_tile_kernel" in k or "head_fused_k" in k)]
         f_kib = sum(fe[k][1] for k in sel) / n
         w_kib = sum(wr.get(k, [0, 0.0, 0.0])[1] for k in sel) / n
         name, nl = "GEMM class: " + ", ".join(sorted(set(k.split("<")[0] for k in sel))), int(sum(fe[k][0] for k in sel) / n)
