@@ -417,26 +417,34 @@ def run_children(args, line: dict, extra_workloads: bool, cpu: bool):
     stdout / stderr (captured into gpurun_out/), so nothing but the final line is printed."""
     import subprocess
     me = os.path.abspath(__file__)
-    os.makedirs(os.path.dirname(WORKLOADS_FILE), exist_ok=True)
+    wfile = WORKLOADS_FILE
+    try:
+        os.makedirs(os.path.dirname(wfile), exist_ok=True)
+        with open(wfile + ".probe", "w"):
+            pass
+        os.remove(wfile + ".probe")
+    except OSError:                     # read-only checkout: the side file goes to the temp directory instead
+        import tempfile
+        wfile = os.path.join(tempfile.gettempdir(), "bench_workloads.json")
     if extra_workloads:
         try:
-            os.remove(WORKLOADS_FILE)
+            os.remove(wfile)
         except OSError:
             pass
-        cmd = [sys.executable, me, "--workloads-child", WORKLOADS_FILE] + (["--workloads", args.workloads] if args.workloads else [])
+        cmd = [sys.executable, me, "--workloads-child", wfile] + (["--workloads", args.workloads] if args.workloads else [])
         rc, note = None, None
         try:
-            with open(WORKLOADS_FILE + ".log", "w") as log:
+            with open(wfile + ".log", "w") as log:
                 rc = subprocess.run(cmd, stdout=log, stderr=subprocess.STDOUT, timeout=900).returncode
         except Exception as e:
             note = "%r" % (e,)
         extras = []
         try:
-            extras = json.load(open(WORKLOADS_FILE))["workloads"]
+            extras = json.load(open(wfile))["workloads"]
         except Exception:
             pass
         line["workloads_summary"] = summarise_workloads(extras)
-        line["workloads_file"] = {"path": os.path.relpath(WORKLOADS_FILE, ROOT), "child_rc": rc, "slices": len(extras)}
+        line["workloads_file"] = {"path": os.path.relpath(wfile, ROOT) if wfile.startswith(ROOT) else wfile, "child_rc": rc, "slices": len(extras)}
         if note:
             line["workloads_file"]["note"] = note[:120]
         worst = next((e for e in extras if e.get("note") == "general_kernel_only" and "ms_per_step" in e), None)
