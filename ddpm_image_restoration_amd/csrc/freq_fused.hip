@@ -21,6 +21,21 @@
 // 256 x 256 x 64) takes 192 us instead of 172 us; the three kernels this replaces took 490 us.  A persistent walk over the
 // tiles with the next tile's x prefetched into registers was slower still (278 us): the hardware's back-filling of finished
 // workgroups overlaps the load phase of one tile with the store phase of another better than a serial tile loop.
+//
+// What bounds it (tools/micro/freq_phase.hip: s_memtime stamps at the phase boundaries, 512 x 512, B = 8, bf16 in / out): 92 % of
+// the 768 workgroup slots are occupied, the shader clock sits at 1.9-2.0 GHz, and a tile lives 15 us of which 5.5 us is the
+// wait for its x (2.5 us even when x is L2-resident: kernel arguments, index arithmetic and the first instructions of three
+// co-resident waves per SIMD), the rest VALU issue -- three waves per SIMD x ~1500 vector instructions x 4 cycles is 70 % of
+// the tile's lifetime.  So the instruction count is the lever, and round 4 took the C = 64 kernel from 3744 to 2074
+// instructions (466 -> 360 us in that microbenchmark, configs[4] bf16 10.96 -> 10.59 ms per timestep on one box):
+//   * pixel addresses: block origins once per thread in 32-bit arithmetic instead of three 64-bit divisions per pixel row
+//     (834 -> 275 instructions in phase A; the 4 x 4-block kernels went from ~9000 to ~1700 instructions);
+//   * operand-row stores with compile-time swizzle keys and immediate offsets; a select instead of a divergent branch per
+//     row in the gate staging; sigmoid through v_rcp_f32 (common.h sigmoid_fast);
+//   * C = 64: the weight fragments of each gate layer are fetched one phase ahead (registers allow it), and the barriers
+//     after that point order LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier), so neither those fetches nor the S stores
+//     of the first half of phase E are waited for at a barrier.
+// Tried and dropped: the DCT's FMA chains as v_pk_fma_f32 with op_sel broadcasts -- see fma2() below.
 #include "kernels.h"
 
 namespace ddpmir {
@@ -28,10 +43,32 @@ namespace ddpmir {
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 namespace {
 
 constexpr int F_ELEMS = 8192;                          // pixels x channels of one tile
+
+// Two FMA chains side by side.  Written for v_pk_fma_f32 (the kernel is bound by VALU issue and the DCT is a quarter of its
+// instructions), but with __builtin_elementwise_fma the kernel's output stopped being reproducible as soon as two workgroups
+// shared a CU (tools/freq_fused_big.py: thousands of wrong values per launch at 256 x 256, none with one workgroup per CU, none
+// with scalar FMAs; the ISA's wait counts look right) -- so these stay two v_fma_f32, and tests/test_gpu_ops.py checks the
+// kernel at sizes with several workgroups per CU.
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
+
+#ifdef DDPMIR_FREQ_PROBE
+__device__ unsigned long long* g_probe;
+// stamps stay in registers until the end of the tile: a store per stamp would put a store round trip into every phase
+// (the workgroup barrier waits for outstanding stores)
+#define PROBE(k) do { probe_t[k] = __builtin_amdgcn_s_memtime(); if ((k) == 8 && threadIdx.x == 0) for (int q_ = 0; q_ < 9; ++q_) g_probe[(size_t)blockIdx.x * 32 + q_] = probe_t[q_]; } while (0)
+// per wave: entry and 'x loads returned' stamps (slots 16 + 2 wave, 17 + 2 wave)
+#define PROBE_WAVE(slot, val) do { if ((threadIdx.x & 63) == 0) g_probe[(size_t)blockIdx.x * 32 + 16 + 2 * (threadIdx.x >> 6) + (slot)] = (val); } while (0)
+#define PROBE_DECL unsigned long long probe_t[9]; const unsigned long long probe_r0 = __builtin_amdgcn_s_memrealtime();
+#else
+#define PROBE(k)
+#define PROBE_DECL
+#define PROBE_WAVE(slot, val)
+#endif
 
 template <int C>
 struct FGeom {
@@ -67,23 +104,40 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
   float* B2s = B1s + C;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nbx = W / BS, nby = H / BS;
-  const int64_t tile = blockIdx.x;
-  // pixel row of the tile -> NHWC pixel index (tiles do not straddle images: host check)
-  auto pix = [&](int row) -> int64_t {
-    const int j = row / BB, rem = row - j * BB, u = rem / BS, v = rem - u * BS;
-    const int64_t gb = tile * NBLK + j;
-    const int bx = (int)(gb % nbx), by = (int)((gb / nbx) % nby), b = (int)(gb / ((int64_t)nbx * nby));
-    return ((int64_t)b * H + by * BS + u) * W + bx * BS + v;
+  const unsigned nbx = W / BS, nby = H / BS;
+  const unsigned tile = blockIdx.x;
+  // Block j of the tile -> its image and the NHWC index of its top-left pixel.  32-bit arithmetic, once per block a thread
+  // touches: as 64-bit divisions per pixel row this index arithmetic was a fifth of the kernel's instructions (the kernel is
+  // bound by instruction issue, tools/micro/freq_phase.hip).  Tiles do not straddle images and B H W < 2^31: host checks.
+  auto origin = [&](int j, int& b) -> int {
+    const unsigned gb = tile * NBLK + j, t = gb / nbx, bx = gb - t * nbx;
+    b = (int)(t / nby);
+    const unsigned by = t - (unsigned)b * nby;
+    return (int)(((unsigned)b * H + by * BS) * W + bx * BS);
   };
   auto is_low = [&](int row) -> bool {
     const int rem = row % BB, u = rem / BS, v = rem - u * BS;
     return u < low && v < low;
   };
+  // Barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global access of the wave: the weight
+  // fragments fetched a phase ahead, the S stores of the first half of phase E -- round trips these barriers need not sit out.
+  auto lds_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   // the wave's quadrant: 32 pixel rows x 64 channels
   const int row0 = C == 64 ? 32 * wave : 32 * (wave & 1);
   const int col0 = C == 64 ? 0 : 64 * (wave >> 1);
+  // a thread's rows of phases A and E are row0 + 4 i + rsub, i < 8: one block (8 x 8 blocks) or two (4 x 4) of the tile
+  constexpr int JW = BB >= 32 ? 1 : 32 / BB;
+  int org[JW], img_b = 0;
+#pragma unroll
+  for (int jj = 0; jj < JW; ++jj) org[jj] = origin(row0 / BB + jj, img_b);
+  auto pix = [&](int i, int rsub_) -> int {             // row0 + 4 i + rsub_, i a compile-time constant after unrolling
+    const int jj = JW == 1 ? 0 : (4 * i) / BB;         // BB < 32: row0 is a multiple of 32, so of BB; rsub_ < 4 never carries
+    const int rem = (row0 % BB) + 4 * i - jj * BB + rsub_;
+    return org[jj] + (rem / BS) * W + rem % BS;
+  };
 
+  PROBE_DECL
+  PROBE(0);
   // ---- phase A: x patch -> LDS (and kept in registers for the final S = x + g * xd)
   const int c4 = lane & 15, rsub = lane >> 4;
   float4 xreg[8];
@@ -91,13 +145,20 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
   for (int i = 0; i < 8; ++i) {
     const int row = row0 + 4 * i + rsub;
     if (xin16) {   // x arrives as bf16 (the producing conv wrote no fp32 copy: half the bytes of this kernel's read)
-      const bf16x4 t = *reinterpret_cast<const bf16x4*>(xin16 + pix(row) * C + col0 + 4 * c4);
+      const bf16x4 t = *reinterpret_cast<const bf16x4*>(xin16 + (int64_t)pix(i, rsub) * C + col0 + 4 * c4);
       xreg[i] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
     } else {
-      xreg[i] = *reinterpret_cast<const float4*>(x + pix(row) * C + col0 + 4 * c4);
+      xreg[i] = *reinterpret_cast<const float4*>(x + (int64_t)pix(i, rsub) * C + col0 + 4 * c4);
     }
     *reinterpret_cast<float4*>(X32 + row * XS + col0 + 4 * c4) = xreg[i];
   }
+#ifdef DDPMIR_FREQ_PROBE
+  {
+    const unsigned long long t_ld = __builtin_amdgcn_s_memtime();   // the LDS stores above waited for the loads
+    PROBE_WAVE(0, probe_t[0]);
+    PROBE_WAVE(1, t_ld);
+  }
+#endif
   if (tid < BB) Ts[tid] = dct[tid];
   if (tid < C) B1s[tid] = b1[tid];
   if (tid < 2 * C) B2s[tid] = b2[tid];
@@ -107,12 +168,19 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
   if constexpr (OP) {
     // attention output rows -> operand rows (16-byte chunks, swizzled), then x = W_o att + b_o + x_in in the fp32 patch
     if (tid < C) B2s[2 * C + tid] = bo[tid];
+    int* orgs = reinterpret_cast<int*>(B2s + 3 * C);   // the operand rows are any rows of the tile: block origins through LDS
+    if (tid < NBLK) { int b_; orgs[tid] = origin(tid, b_); }
+    __syncthreads();
+    auto pix_any = [&](int row) -> int64_t {
+      const int rem = row % BB;
+      return (int64_t)orgs[row / BB] + (rem / BS) * W + rem % BS;
+    };
     constexpr int CH = G::PT * CPR / 256;              // chunks per thread: 4
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int q = i * 256 + tid, row = q / CPR, p = q % CPR;
       *reinterpret_cast<bf16x8*>(A16 + row * ROWB + ((p ^ ((row >> RSH) & (CPR - 1))) << 4)) =
-          *reinterpret_cast<const bf16x8*>(att16 + pix(row) * C + 8 * p);
+          *reinterpret_cast<const bf16x8*>(att16 + pix_any(row) * C + 8 * p);
     }
     __syncthreads();
     f32x16 acc0[2];
@@ -147,15 +215,35 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
     for (int i = 0; i < 8; ++i) xreg[i] = *reinterpret_cast<const float4*>(X32 + (row0 + 4 * i + rsub) * XS + col0 + 4 * c4);
   }
   __syncthreads();
+  PROBE(1);
 
   // ---- phase B: block DCT in place (fp32) + bf16 operand rows.  Same FMA order as block_transform_fast_k.
-  auto put16 = [&](int row, int c, float v) {
-    *reinterpret_cast<__bf16*>(A16 + row * ROWB + (((c >> 3) ^ ((row >> RSH) & (CPR - 1))) << 4) + (c & 7) * 2) = (__bf16)v;
+  // operand-row stores: row = rb + rc with rb a multiple of 32 (runtime) and rc a compile-time constant after unrolling, so the
+  // row's swizzle key is the constant's -- one XOR per distinct key and immediate offsets instead of the address arithmetic per
+  // element (cc = the channel's chunk << 4, cl = its byte in the chunk)
+  auto put16 = [&](unsigned char* rowbase, int rc, int cc, float v) {
+    *reinterpret_cast<__bf16*>(rowbase + rc * ROWB + (cc ^ (((rc >> RSH) & (CPR - 1)) << 4))) = (__bf16)v;
   };
+  // C = 64: the weight fragments of both gate layers (32 registers each) are fetched a phase ahead of their GEMM, so the L2
+  // round trip runs under the DCT / the hidden-row stores instead of in front of the MFMAs; C = 128 has no registers for that
+  constexpr bool PRE = C == 64;
+  bf16x8 w1f[PRE ? KS : 1][2], w2f[2][PRE ? KK : 1][2];
+  auto fetch_w1 = [&]() {
+    if constexpr (PRE) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) w1f[ks][nt] = *reinterpret_cast<const bf16x8*>(w1 + (size_t)(col0 + nt * 32 + lr) * C + (2 * ks + lh) * 8);
+    }
+  };
+  if constexpr (BS != 8) fetch_w1();
   if constexpr (BS == 8) {
     // 128 (block, channel) pairs, two threads each: pass 1 = T X on four columns, pass 2 = (T X) T^T on four rows
     const int pair = tid & 127, c = pair % C, j = pair / C, half = tid >> 7;
     float* base = X32 + (j * 64) * XS + c;
+    unsigned char* ob = A16 + (j * 64 + 32 * half) * ROWB + (c & 7) * 2;
+    float* xb = X32 + (j * 64 + 32 * half) * XS + c;
+    const int cc = (c >> 3) << 4;
     {
       float xv[8][4], tm[8][4];
 #pragma unroll
@@ -165,11 +253,12 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          float a = 0.f;
+        for (int v = 0; v < 4; v += 2) {
+          f32x2 a = {0.f, 0.f};
 #pragma unroll
-          for (int k = 0; k < 8; ++k) a = fmaf(Ts[u * 8 + k], xv[k][v], a);
-          tm[u][v] = a;
+          for (int k = 0; k < 8; ++k) a = fma2(f32x2{Ts[u * 8 + k], Ts[u * 8 + k]}, f32x2{xv[k][v], xv[k][v + 1]}, a);
+          tm[u][v] = a[0];
+          tm[u][v + 1] = a[1];
         }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
@@ -177,6 +266,8 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
         for (int v = 0; v < 4; ++v) base[(u * 8 + 4 * half + v) * XS] = tm[u][v];
     }
     __syncthreads();
+    PROBE(2);
+    fetch_w1();
     {
       float tm[4][8];
 #pragma unroll
@@ -186,13 +277,16 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
 #pragma unroll
       for (int v = 0; v < 8; ++v)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          float a = 0.f;
+        for (int u = 0; u < 4; u += 2) {
+          f32x2 a = {0.f, 0.f};
 #pragma unroll
-          for (int k = 0; k < 8; ++k) a = fmaf(tm[u][k], Ts[v * 8 + k], a);
-          const int row = j * 64 + (4 * half + u) * 8 + v;
-          X32[row * XS + c] = a;
-          put16(row, c, a);
+          for (int k = 0; k < 8; ++k) a = fma2(f32x2{tm[u][k], tm[u + 1][k]}, f32x2{Ts[v * 8 + k], Ts[v * 8 + k]}, a);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int rc = (u + e) * 8 + v;              // row j * 64 + 32 * half + rc
+            xb[rc * XS] = a[e];
+            put16(ob, rc, cc, a[e]);
+          }
         }
     }
   } else {
@@ -209,26 +303,31 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          float a = 0.f;
+        for (int v = 0; v < 4; v += 2) {
+          f32x2 a = {0.f, 0.f};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) a = fmaf(Ts[u * 4 + k], xv[k][v], a);
-          tm[u][v] = a;
+          for (int k = 0; k < 4; ++k) a = fma2(f32x2{Ts[u * 4 + k], Ts[u * 4 + k]}, f32x2{xv[k][v], xv[k][v + 1]}, a);
+          tm[u][v] = a[0];
+          tm[u][v + 1] = a[1];
         }
 #pragma unroll
       for (int v = 0; v < 4; ++v)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          float a = 0.f;
+        for (int u = 0; u < 4; u += 2) {
+          f32x2 a = {0.f, 0.f};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) a = fmaf(tm[u][k], Ts[v * 4 + k], a);
-          const int row = j * 16 + u * 4 + v;
-          X32[row * XS + c] = a;
-          put16(row, c, a);
+          for (int k = 0; k < 4; ++k) a = fma2(f32x2{tm[u][k], tm[u + 1][k]}, f32x2{Ts[v * 4 + k], Ts[v * 4 + k]}, a);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int row = j * 16 + (u + e) * 4 + v;
+            X32[row * XS + c] = a[e];
+            *reinterpret_cast<__bf16*>(A16 + row * ROWB + (((c >> 3) ^ ((row >> RSH) & (CPR - 1))) << 4) + (c & 7) * 2) = (__bf16)a[e];
+          }
         }
     }
   }
   __syncthreads();
+  PROBE(3);
 
   // ---- phase C: hid = lrelu(W1 xd16 + b1); the hidden layer then overwrites the operand rows
   f32x16 acc1[2];
@@ -241,19 +340,35 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
     const bf16x8 af = *reinterpret_cast<const bf16x8*>(arow_p + (((2 * ks + lh) ^ a_key) << 4));
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(w1 + (size_t)(col0 + nt * 32 + lr) * C + (2 * ks + lh) * 8);
+      bf16x8 bfr;
+      if constexpr (PRE) bfr = w1f[ks][nt];
+      else bfr = *reinterpret_cast<const bf16x8*>(w1 + (size_t)(col0 + nt * 32 + lr) * C + (2 * ks + lh) * 8);
       acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc1[nt], 0, 0, 0);
     }
   }
-  __syncthreads();       // every wave has read its operand rows before anybody overwrites them
+  if constexpr (PRE) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          w2f[g][kk][q] = *reinterpret_cast<const bf16x8*>(w2 + (size_t)(g * C + col0 + q * 32 + lr) * C + (2 * (g * KK + kk) + lh) * 8);
+  }
+  lds_sync();            // every wave has read its operand rows before anybody overwrites them
+  PROBE(4);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int col = col0 + nt * 32 + lr;
     const float bc = B1s[col];
+    // row = row0 + 4 lh + rc: the key of 4 lh (bit 2 of the row) and of the constant rc (bits 0, 1, 3, 4) do not overlap
+    unsigned char* hb = A16 + (row0 + 4 * lh) * ROWB + (col & 7) * 2;
+    const int cc = ((col >> 3) ^ (((4 * lh) >> RSH) & (CPR - 1))) << 4;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) put16(row0 + (r & 3) + 8 * (r >> 2) + 4 * lh, col, act_apply(acc1[nt][r] + bc, ACT_LRELU));
+    for (int r = 0; r < 16; ++r) put16(hb, (r & 3) + 8 * (r >> 2), cc, act_apply(acc1[nt][r] + bc, ACT_LRELU));
   }
-  __syncthreads();
+  lds_sync();
+  PROBE(5);
 
   // ---- phase D: gate pre-activations of the wave's 64 channels: low gate = W2[c] hid[0:C/2], high gate = W2[C + c] hid[C/2:C]
   f32x16 acc2[4];
@@ -269,16 +384,20 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
       const bf16x8 hf = *reinterpret_cast<const bf16x8*>(arow_p + (((2 * ks + lh) ^ a_key) << 4));
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const bf16x8 bw = *reinterpret_cast<const bf16x8*>(w2 + (size_t)(g * C + col0 + q * 32 + lr) * C + (2 * ks + lh) * 8);
+        bf16x8 bw;
+        if constexpr (PRE) bw = w2f[g][kk][q];
+        else bw = *reinterpret_cast<const bf16x8*>(w2 + (size_t)(g * C + col0 + q * 32 + lr) * C + (2 * ks + lh) * 8);
         acc2[2 * g + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, bw, acc2[2 * g + q], 0, 0, 0);
       }
     }
-  __syncthreads();       // the operand rows are dead from here: that region becomes the waves' staging tiles
+  lds_sync();            // the operand rows are dead from here: that region becomes the waves' staging tiles
+  PROBE(6);
 
   // ---- phase E: per pixel keep its gate, S = x + sigmoid(.) * xd (* boost for the high gate), row-contiguous bf16 stores
   // (two halves of 16 rows per wave: 4 waves x 16 x 64 floats = the 16 KiB of the operand rows)
   float* st = reinterpret_cast<float*>(A16) + wave * (16 * 64);
-  const float bs = boost[(int)(tile * NBLK / ((int64_t)nbx * nby))];
+  const float bs = boost[img_b];
+  const float b2lo[2] = {B2s[col0 + lr], B2s[col0 + 32 + lr]}, b2hi[2] = {B2s[C + col0 + lr], B2s[C + col0 + 32 + lr]};
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -287,31 +406,37 @@ __global__ __launch_bounds__(256, 3) void freq_gate_fused_k(const float* __restr
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;              // 16 hh .. 16 hh + 15
       const bool lowp = is_low(row0 + row);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int col = q * 32 + lr;
-        st[(row - 16 * hh) * 64 + col] = lowp ? acc2[q][r] + B2s[col0 + col] : acc2[2 + q][r] + B2s[C + col0 + col];
-      }
+      for (int q = 0; q < 2; ++q)                                    // both sums, then a select: no divergent branch per row
+        st[(row - 16 * hh) * 64 + q * 32 + lr] = lowp ? acc2[q][r] + b2lo[q] : acc2[2 + q][r] + b2hi[q];
     }
-    __syncthreads();
+    lds_sync();
 #pragma unroll
     for (int i4 = 0; i4 < 4; ++i4) {
       const int i = 4 * hh + i4, row = 4 * i + rsub, grow = row0 + row;
       float4 v = *reinterpret_cast<const float4*>(st + (row - 16 * hh) * 64 + 4 * c4);
       const float4 xd = *reinterpret_cast<const float4*>(X32 + grow * XS + col0 + 4 * c4);
-      v.x = act_apply(v.x, ACT_SIGMOID); v.y = act_apply(v.y, ACT_SIGMOID); v.z = act_apply(v.z, ACT_SIGMOID); v.w = act_apply(v.w, ACT_SIGMOID);
+      v.x = sigmoid_fast(v.x); v.y = sigmoid_fast(v.y); v.z = sigmoid_fast(v.z); v.w = sigmoid_fast(v.w);   // = act16(., ACT_SIGMOID) of the GEMM epilogue
       v.x *= xd.x; v.y *= xd.y; v.z *= xd.z; v.w *= xd.w;
       if (!is_low(grow)) { v.x *= bs; v.y *= bs; v.z *= bs; v.w *= bs; }
       v.x += xreg[i].x; v.y += xreg[i].y; v.z += xreg[i].z; v.w += xreg[i].w;
       if (S8) {   // operand of an e4m3 conv_out (DDPMIR_FP8)
-        *reinterpret_cast<unsigned*>(S8 + pix(grow) * C + col0 + 4 * c4) = pack_e4m3x4(v);
+        *reinterpret_cast<unsigned*>(S8 + (int64_t)pix(i, rsub) * C + col0 + 4 * c4) = pack_e4m3x4(v);
       } else {
         bf16x4 o;
         o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(S16 + pix(grow) * C + col0 + 4 * c4) = o;
+#ifdef DDPMIR_FREQ_PROBE_NOSTORE
+        if (v.x == 12345.678f)       // experiment of tools/micro/freq_phase.hip: the kernel without its stores
+#endif
+        *reinterpret_cast<bf16x4*>(S16 + (int64_t)pix(i, rsub) * C + col0 + 4 * c4) = o;
       }
     }
-    __syncthreads();     // the staging rows are free for the second half
+    if (hh == 0) lds_sync();     // the staging rows are free for the second half
+    if (hh == 0) PROBE(7);
   }
+  PROBE(8);
+#ifdef DDPMIR_FREQ_PROBE
+  if (threadIdx.x == 0) { g_probe[(size_t)blockIdx.x * 32 + 24] = probe_r0; g_probe[(size_t)blockIdx.x * 32 + 25] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 template <int BS, int C, bool OP>
@@ -319,7 +444,7 @@ void launch_t(const float* x, const float* dct, const void* w1, const float* b1,
               void* S16, int B, int H, int W, int low, const void* att16, const void* wo, const float* bo, hipStream_t s, void* S8,
               const void* xin16) {
   using G = FGeom<C>;
-  constexpr int LDS = G::X32_BYTES + G::A16_BYTES + (BS * BS + C + 2 * C + (OP ? C : 0)) * 4;
+  constexpr int LDS = G::X32_BYTES + G::A16_BYTES + (BS * BS + C + 2 * C + (OP ? C + 8 : 0)) * 4;
   static PerDeviceOnce attr;
   attr.run([] {
     DDPMIR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&freq_gate_fused_k<BS, C, OP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));

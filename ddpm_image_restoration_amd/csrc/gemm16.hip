@@ -795,7 +795,7 @@ __global__ void splitk_reduce_k(const IGemm p, int nsplit, int64_t M, int HW) {
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     // (the rest of the main kernel's epilogue, in its order: activation, elementwise factor, per-sample factor)
-    if (p.epi_act != ACT_NONE) { v.x = act_apply(v.x, p.epi_act); v.y = act_apply(v.y, p.epi_act); v.z = act_apply(v.z, p.epi_act); v.w = act_apply(v.w, p.epi_act); }
+    if (p.epi_act != ACT_NONE) { v.x = act16(v.x, p.epi_act); v.y = act16(v.y, p.epi_act); v.z = act16(v.z, p.epi_act); v.w = act16(v.w, p.epi_act); }
     if (p.mul) { const float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + n); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
     if (p.rowscale) { const float rs = p.rowscale[m / HW]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
     if (p.res) { const float4 t = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }

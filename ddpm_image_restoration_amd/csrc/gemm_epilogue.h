@@ -186,7 +186,7 @@ __device__ __forceinline__ void gemm16_epilogue(const IGemm& p, f32x16 (&acc)[NT
       if (p.sel_C && is_low_freq(y, x, p.H, p.W, p.bs, p.low) == hi_cols) continue;   // the other gate owns this pixel
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
       if (p.tb) { float4 t = *reinterpret_cast<const float4*>(p.tb + (size_t)b * p.ldtb + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-      if (p.epi_act != ACT_NONE) { v.x = act_apply(v.x, p.epi_act); v.y = act_apply(v.y, p.epi_act); v.z = act_apply(v.z, p.epi_act); v.w = act_apply(v.w, p.epi_act); }
+      if (p.epi_act != ACT_NONE) { v.x = act16(v.x, p.epi_act); v.y = act16(v.y, p.epi_act); v.z = act16(v.z, p.epi_act); v.w = act16(v.w, p.epi_act); }
       if (p.mul) { float4 t = *reinterpret_cast<const float4*>(p.mul + (size_t)m * p.ldmul + no); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
       if (p.rowscale && (!p.sel_C || hi_cols)) { const float rs = p.rowscale[b]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
       if (p.epi_mask != MASK_NONE) {

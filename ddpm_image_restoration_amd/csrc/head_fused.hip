@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void head_fused_k(const void* __restrict__ xin
       for (int j = 0; j < 8; ++j) o[j] = (__bf16)0.f;
       if (inside & (1u << it)) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)act_apply(fmaf((float)raw[it][j], sc[j], sh[j]), ACT_SILU);   // = gn_apply16_k's operand
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)act16(fmaf((float)raw[it][j], sc[j], sh[j]), ACT_SILU);   // = gn_apply16_k's operand
       }
       *reinterpret_cast<bf16x8*>(lds + p * 128 + ((ch ^ ((p >> 1) & 7)) << 4)) = o;
     }

@@ -619,6 +619,30 @@ def test_frequency_block_one_pass_kernel(ops, B, H, W, bs, low, C):
     assert np.abs(nchw(f2) - nchw(fused)).max() > 0.05 and np.isfinite(f2).all() and np.abs(x2).max() < 50
 
 
+@pytest.mark.parametrize("B,H,W,bs,low,C", [(2, 256, 256, 8, 4, 64), (4, 128, 128, 8, 4, 128), (2, 256, 256, 4, 3, 64)])
+def test_frequency_block_one_pass_kernel_with_several_workgroups_per_cu(ops, B, H, W, bs, low, C):
+    """The shapes of the test above launch at most 64 tiles -- one workgroup per CU.  A v_pk_fma_f32 form of the kernel's DCT
+    passed them bit for bit and produced thousands of wrong values per launch, different ones each time, once two workgroups
+    shared a CU.  Here: 1024 tiles (three workgroups per CU), equality with the three-kernel path, with and
+    without the attention's output projection formed inside, and the same bits on every call."""
+    from ddpm_image_restoration_amd.synth import dct_matrix
+    x = rnd(B, C, H, W, seed=60)
+    D = dct_matrix(bs)
+    w1, b1 = rnd(C, C, seed=61, scale=0.2), rnd(C, seed=62, scale=0.3)
+    w2 = rnd(2 * C, C, seed=63, scale=0.3)
+    w2[:C, C // 2:] = 0; w2[C:, :C // 2] = 0
+    b2 = rnd(2 * C, seed=64, scale=0.3)
+    boost = np.abs(rnd(B, seed=65)) + 0.5
+    att, wo, bo = rnd(B, C, H, W, seed=66), rnd(C, C, seed=67, scale=0.15), rnd(C, seed=68, scale=0.2)
+    three = ops.freq_gates_bf16(nhwc(x), D, w1, b1, w2, b2, boost, low, fused=False)
+    three_op = ops.freq_gates_bf16(nhwc(x), D, w1, b1, w2, b2, boost, low, fused=False, att=nhwc(att), wo=wo, bo=bo)
+    for rep in range(3):
+        f = ops.freq_gates_bf16(nhwc(x), D, w1, b1, w2, b2, boost, low, fused=True)
+        f_op = ops.freq_gates_bf16(nhwc(x), D, w1, b1, w2, b2, boost, low, fused=True, att=nhwc(att), wo=wo, bo=bo)
+        assert int((f != three).sum()) == 0, (rep, int((f != three).sum()), float(np.abs(f - three).max()))
+        assert int((f_op != three_op).sum()) == 0, (rep, int((f_op != three_op).sum()), float(np.abs(f_op - three_op).max()))
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(2, 128, 128, 64, 64, 3), (3, 192, 224, 64, 64, 3), (1, 160, 224, 32, 32, 3), (2, 32, 32, 3, 64, 3),
                                               (2, 16, 16, 64, 32, 1), (4, 96, 96, 128, 64, 3), (3, 128, 96, 64, 32, 3), (9, 128, 128, 64, 64, 3),
                                               (2, 64, 64, 64, 64, 1), (5, 7, 3, 36, 40, 3), (3, 200, 232, 64, 64, 3)])
