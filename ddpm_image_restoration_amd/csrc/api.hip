@@ -195,7 +195,7 @@ int ddpmir_profile_read(ddpmir_ctx* ctx, const char* cls, double* ms, int64_t* l
 #ifndef DDPMIR_HIPCC_VERSION
 #define DDPMIR_HIPCC_VERSION "unknown"
 #endif
-const char* ddpmir_version(void) { return "ddpmir 0.3.0 (gfx950) src=" DDPMIR_SRC_HASH " hipcc=" DDPMIR_HIPCC_VERSION; }
+const char* ddpmir_version(void) { return "ddpmir 0.4.0 (gfx950) src=" DDPMIR_SRC_HASH " hipcc=" DDPMIR_HIPCC_VERSION; }
 
 int ddpmir_set_option(ddpmir_ctx* ctx, const char* name, double value) {
   return guarded(ctx, [&] {
