@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
                        "D GEMM2 (W2 from L2)", "E half 0 (gate, S, store)", "E half 1"};
   double tot = 0;
   for (int k = 1; k < 9; ++k) tot += sum[k] / cnt;
-  printf("phase means over %zu tiles, s_memtime ticks (shader clock, ~2.4 GHz)\n", cnt);
+  printf("phase means over %zu tiles, s_memtime ticks (shader clock; the line below the table gives its rate)\n", cnt);
   for (int k = 1; k < 9; ++k) printf("  %-32s %8.1f  (%4.1f %%)\n", nm[k], sum[k] / cnt, 100 * sum[k] / cnt / tot);
   printf("  %-32s %8.1f\n", "tile lifetime", tot);
   // per wave: how long after the first wave of its workgroup it entered, and entry -> x loads returned
