@@ -136,3 +136,19 @@ def test_frequency_kernel_isa(tmp_path):
             assert re.search(r"\.vgpr_spill_count:\s+0\b", meta), nm
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)) <= 168, nm        # three workgroups per CU
     assert count[("8", "64", "0")] < 2300 and count[("8", "64", "1")] < 2650 and count[("4", "64", "0")] < 1900, count
+    # no register is read or overwritten while the load that writes it may still be in flight (tools/micro/waitcnt_check.py);
+    # the checker itself has teeth: weakening every lgkmcnt(0) by one is noticed
+    sys.path.insert(0, MICRO)
+    try:
+        import waitcnt_check as Wc
+    finally:
+        sys.path.pop(0)
+    seen = 0
+    for nm, body in Wc.kernels(asm):
+        if "freq_gate_fused_k" not in nm:
+            continue
+        seen += 1
+        assert Wc.check(body, nm, verbose=False) == [], nm
+        if "ILi8ELi64ELb0E" in nm:
+            assert len(Wc.check([l.replace("lgkmcnt(0)", "lgkmcnt(1)") for l in body], nm, verbose=False)) > 100
+    assert seen == 8
